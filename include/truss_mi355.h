@@ -1,0 +1,192 @@
+/*
+ * truss_mi355.h -- C ABI of the MI355X-native batched 2-D truss FEM environment step.
+ *
+ * This is the drop-in boundary for the hot path of kupc25648/MOP-truss-MARL.
+ * The reference has no FFI of its own: its boundary is Python duck typing between
+ * master_DDPG_truss2D_MO.py and truss2D_ENV.Game_research04.  The entry points below are what a
+ * binding for that path needs; each one cites the reference interface it replaces
+ * (paths relative to the reference checkout, train/code/ unless a test copy is named).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).
+ *   - every pointer inside truss_step_args_t is DEVICE memory owned by the caller; the library
+ *     never allocates per call and never synchronises the stream (safe inside hipGraph capture).
+ *   - all functions return TRUSS_OK (0) or a negative error code; truss_last_error() gives text.
+ *   - batch layout is struct-of-arrays with the env index outermost: a[B][N], a[B][E], ...
+ *   - heights/actions/observations are float32 exactly as in the reference's state arrays; the
+ *     stiffness assembly and the solve are float64 (SURVEY.md §7 "Precision").
+ */
+#ifndef TRUSS_MI355_H
+#define TRUSS_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRUSS_ABI_VERSION 1
+
+#define TRUSS_OK 0
+#define TRUSS_EINVAL (-1)       /* bad argument (NULL, size mismatch, pair table not an involution ...) */
+#define TRUSS_EUNSUPPORTED (-2) /* topology outside the compiled kernel envelope (bandwidth, N, E) */
+#define TRUSS_EHIP (-3)         /* a HIP runtime call failed */
+#define TRUSS_ENOMEM (-4)
+
+/* flags for truss_step_args_t.flags */
+#define TRUSS_F_NO_DECODE 0x1u     /* analysis only: y_out = y_in, sec_out = sec_in (reset path) */
+#define TRUSS_F_CLAMP_INPLACE 0x2u /* write the clamped actions back into a_geo / a_topo
+                                      (truss2D_ENV.py:376-388 mutates the caller's arrays) */
+
+/* columns of env_params[B][TRUSS_NPARAM] (float64) */
+#define TRUSS_NPARAM 8
+#define TRUSS_P_YMAX 0    /* gen_model.y_max            truss2D_GEN.py:80  */
+#define TRUSS_P_DMIN 1    /* gen_model.d_min            truss2D_GEN.py:82  */
+#define TRUSS_P_MAXDEF 2  /* gen_model.max_deformation  truss2D_GEN.py:78  */
+#define TRUSS_P_LOADX 3   /* Load.size[0]               truss2D_GEN.py:362-364 */
+#define TRUSS_P_LOADY 4   /* Load.size[1] */
+#define TRUSS_P_INTOBJ1 5 /* Game_research04.int_obj1   truss2D_ENV.py:273 */
+#define TRUSS_P_INTOBJ2 6 /* Game_research04.int_obj2   truss2D_ENV.py:274 */
+#define TRUSS_P_ISROOF 7  /* truss_type == 'roof' (1.0) / 'bridge' (0.0)  truss2D_GEN.py:70 */
+
+typedef struct truss_topo truss_topo_t; /* opaque: host + device tables of one topology */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int truss_abi_version(void);
+const char *truss_last_error(void);
+/* "hip" for the product library; the CPU lane emulator used by the build's own tests says "emu". */
+const char *truss_backend(void);
+
+/* ---- topology (reset time) ----------------------------------------------------------------
+ * Replaces Model.add_node/add_element + gen_nsc/gen_tnsc/gen_ndof + the ttnsc half of gen_ssm
+ * (FEM_2Dtruss.py:189-198, 227-261, 310-317) and the static output of gen_model.generate
+ * (truss2D_GEN.py:241-434): connectivity, supports, top_node, vertical_pair, load placement.
+ *
+ *   conn[E][2]        0-based node indices (element.nodes[0], element.nodes[1])
+ *   res[N][2]         Node.res (1 = restrained)
+ *   top[N]            Node.top_node
+ *   pair[N]           index of Node.vertical_pair[0]; must be an involution without fixed points when
+ *                     the action decode is used; may be NULL for analysis-only topologies
+ *   load_mask[2][N]   nodes that carry the load for bridge (row 0) / roof (row 1)
+ *                     (truss2D_GEN.py:421-430); NULL = derive by that rule from top/res
+ *   sym_nodes[n][2]   (dst, src): y[dst] = y[src] when coin != 0, y[src] = y[dst] when coin == 0
+ *                     (hard-coded mirror blocks of test/<star>/code/truss2D_ENV.py:459-553 / :459-675);
+ *                     n = 0 for the train copy
+ *   sym_elems[n][2]   both elements take min(section) (same blocks)
+ *   sections[S][2]    area [m^2], inertia [m^4]  (section_data/01_brace_rod2.csv * 1e-4 / 1e-8,
+ *                     truss2D_GEN.py:63-64, 291-292)
+ *   node_order[N]     optional hint: node ordering for the banded solver (NULL = library chooses)
+ */
+int truss_topo_create(truss_topo_t **out, int32_t n_nodes, int32_t n_elems, const int32_t *conn,
+                      const uint8_t *res, const uint8_t *top, const int32_t *pair,
+                      const uint8_t *load_mask, int32_t n_sym_nodes, const int32_t *sym_nodes,
+                      int32_t n_sym_elems, const int32_t *sym_elems, int32_t n_sections,
+                      const double *sections, double e_mod, double long_stress,
+                      const int32_t *node_order);
+int truss_topo_destroy(truss_topo_t *t);
+
+/* DOF numbering exactly as the reference computes it (bit-exact integers):
+ *   nsc[2N]    Model.nsc   (FEM_2Dtruss.py:227-245), 1-based, free DOFs first
+ *   ttnsc[E][4] Model.ttnsc (FEM_2Dtruss.py:311-317)
+ * returns ndof (FEM_2Dtruss.py:255-261) or a negative error. Host pointers, may be NULL. */
+int truss_topo_dofs(const truss_topo_t *t, int32_t *nsc, int32_t *ttnsc);
+
+/* Solver view of the same system: perm[ndof] = reference DOF id (0-based) at solver position i,
+ * half_bandwidth of K under that ordering, and the kernel window (lanes-per-env x rows-per-lane)
+ * that was selected.  Host pointers, may be NULL. */
+int truss_topo_solver_info(const truss_topo_t *t, int32_t *perm, int32_t *half_bandwidth,
+                           int32_t *lanes_per_env, int32_t *rows_per_lane);
+
+/* ---- the batched environment step ----------------------------------------------------------
+ * One Game_research04._game_modify(set_node, set_element, nC_e, actions) per env
+ * (truss2D_ENV.py:370-525): clamp -> _set_model -> geometry move -> supports/round -> section
+ * +-1 -> sequential height repairs -> [symmetry] -> set_moveRange -> Model.gen_all -> objectives.
+ * With TRUSS_F_NO_DECODE it is Model.restore(); Model.gen_all() + the objective sums of
+ * Game_research04.__init__ (truss2D_ENV.py:264-274) = the reset path (_game_get_1_state :336-340).
+ */
+typedef struct truss_step_args {
+  size_t struct_size; /* = sizeof(truss_step_args_t), ABI guard */
+  int32_t n_envs;     /* B */
+  uint32_t flags;
+
+  /* design state in (device) */
+  const float *x;         /* [B][N]   node x (Node.coord[0]) */
+  const float *y_in;      /* [B][N]   set_node[:,1]   (truss2D_ENV.py:362) */
+  const int32_t *sec_in;  /* [B][E]   set_element[:,0] (truss2D_ENV.py:366) */
+  const float *max_up_in; /* [B][N] or NULL. The reference uses the move ranges left on its model by
+                             the PREVIOUS analysis (truss2D_ENV.py:402,407); NULL = recompute from
+                             y_in (the ranges the parent design itself has, nN_x_n[:,7:9]) */
+  const float *max_down_in;
+  float *a_geo;           /* [B][N][2] actions[0]; written only with TRUSS_F_CLAMP_INPLACE */
+  float *a_topo;          /* [B][N][3] actions[1] */
+  const uint8_t *coin;    /* [B] or NULL: 1 when random.random() >= 0.5 (test copies :459) */
+  const float *target;    /* [B][N]   Node.target of top nodes (truss2D_GEN.py:369-374) */
+  const double *env_params; /* [B][TRUSS_NPARAM] */
+
+  /* design state out */
+  float *y_out;        /* [B][N] */
+  int32_t *sec_out;    /* [B][E] */
+  float *max_up_out;   /* [B][N] or NULL  set_moveRange of the new design (truss2D_GEN.py:118-133) */
+  float *max_down_out; /* [B][N] or NULL */
+
+  /* analysis results */
+  float *disp;      /* [B][N][2] Node.global_d (FEM_2Dtruss.py:341-352); restrained DOFs = 0 */
+  float *q0;        /* [B][E]    Element.e_q[0][0] (FEM_2Dtruss.py:383-386) */
+  float *sr;        /* [B][E]    Element.prop_yeield (FEM_2Dtruss.py:414-431) */
+  uint8_t *comp;    /* [B][E]    Element.iscompress */
+  float *point;     /* [B][4]    [obj1/int_obj1, obj2/int_obj2, con1, con2] (truss2D_ENV.py:518-523) */
+  float *obj;       /* [B][2] or NULL: raw obj1, obj2 (= int_obj1/2 when called at reset) */
+  double *disp_f64; /* [B][N][2] or NULL: float64 copy for solver-level parity checks */
+  double *q0_f64;   /* [B][E] or NULL */
+  double *energy;   /* [B] or NULL: Model.U_full (FEM_2Dtruss.py:374-379) */
+  double *reactions; /* [B][2N-ndof] or NULL: Model.r[ndof:] (FEM_2Dtruss.py:393-411) */
+  int32_t *status;  /* [B] or NULL: 0 ok, 1 = non-positive pivot (K not SPD: the reference would
+                       raise numpy.linalg.LinAlgError from FEM_2Dtruss.py:337 or return garbage) */
+} truss_step_args_t;
+
+int truss_step(const truss_topo_t *t, const truss_step_args_t *args, void *stream);
+
+/* Launch `n_steps` chained steps without returning to the host in between: step s reads design
+ * state from buffer (s & 1) and writes buffer ((s+1) & 1); actions for step s are taken at
+ * a_geo + (s % n_action_sets) * B*N*2 (resp. a_topo ... *3).  Used by rollouts and bench.py so the
+ * per-step host overhead is one kernel launch.  args->y_in/sec_in = buffer 0, y_out/sec_out =
+ * buffer 1; all other outputs are overwritten every step. */
+int truss_rollout(const truss_topo_t *t, const truss_step_args_t *args, int32_t n_steps,
+                  int32_t n_action_sets, void *stream);
+
+/* ---- observation tensors ---------------------------------------------------------------------
+ * state_data + state_data_not_norm (truss2D_ENV.py:40-193) for the design/analysis a truss_step
+ * just produced.  A_n, mask and nC_e are topology-static and are NOT written per env (the host
+ * mirror builds them once).  All outputs float32, any of them may be NULL.
+ */
+typedef struct truss_obs_args {
+  size_t struct_size;
+  int32_t n_envs;
+  uint32_t flags;
+  const float *x;          /* [B][N] */
+  const float *y;          /* [B][N]  (truss_step y_out) */
+  const int32_t *sec;      /* [B][E] */
+  const float *max_up;     /* [B][N] */
+  const float *max_down;   /* [B][N] */
+  const float *target;     /* [B][N] */
+  const float *disp;       /* [B][N][2] */
+  const float *q0;         /* [B][E] */
+  const float *sr;         /* [B][E] */
+  const uint8_t *comp;     /* [B][E] */
+  const double *env_params; /* [B][TRUSS_NPARAM] */
+  float *x_n;     /* [B][N][13]  normalised node features (truss2D_ENV.py:50-102) */
+  float *A_s;     /* [B][N][N]   area / max area on edges (:86-87) */
+  float *A_n_ts;  /* [B][N][N]   tension stress ratio on edges (:92-97) */
+  float *A_n_cs;  /* [B][N][N]   compression stress ratio on edges (:98-100) */
+  float *nN_x_n;  /* [B][N][12]  raw node features (:134-146) */
+  float *nN_x_e;  /* [B][E][21]  raw element features (:148-169) */
+} truss_obs_args_t;
+
+int truss_obs(const truss_topo_t *t, const truss_obs_args_t *args, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRUSS_MI355_H */

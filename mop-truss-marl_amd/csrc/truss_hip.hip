@@ -1,0 +1,118 @@
+// truss_hip.hip -- gfx950 (MI355X / CDNA4) backend of include/truss_mi355.h.
+//
+// One 64-lane wavefront per workgroup; G lanes own one env (64/G envs per wave).  The lane program
+// and its phase schedule live in truss_body.h, the host logic in truss_host.h.  Everything an env
+// needs between the first load and the last store stays in LDS/registers: the assembled band of K
+// (n_pad x W float64), its L*D factor (in place), the load vector and the solution.  HBM sees only
+// the algorithmic bytes of the step (DESIGN.md "bytes per env-step").
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#pragma clang fp contract(off)  // float32 decode arithmetic must round like numpy: no implicit FMA
+
+#define TRUSS_HD __device__ __forceinline__
+#define TRUSS_UNROLL _Pragma("unroll")
+
+// LDS float64 scatter-add (ds_add_f64 on gfx950)
+__device__ __forceinline__ void tb_lds_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// 1/d for the pivot: v_rcp_f64 seed + two Newton steps (full double accuracy for normal d)
+__device__ __forceinline__ double tb_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+#include "truss_body.h"
+
+template <int G, int RPL, int EPL>
+__global__ __launch_bounds__(64) void truss_step_kernel(const TopoDev T, const StepArgsDev A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  StepLane<G, RPL, EPL> ln;
+  ln.init(threadIdx.x, blockIdx.x, T, A, smem);
+  constexpr int W_ = StepLane<G, RPL, EPL>::W;
+#define PH(call) \
+  ln.call;       \
+  __syncthreads()
+#define PH_NS(call) ln.call
+#define BAR() __syncthreads()
+  TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
+#undef PH
+#undef PH_NS
+#undef BAR
+}
+
+__global__ __launch_bounds__(64) void truss_obs_kernel(const TopoDev T, const ObsArgsDev A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ObsLane ln;
+  ln.init(threadIdx.x, blockIdx.x, T, A, smem);
+#define PH(call) \
+  ln.call;       \
+  __syncthreads()
+#define PH_NS(call) ln.call
+  TRUSS_OBS_SCHEDULE(PH, PH_NS, T, A)
+#undef PH
+#undef PH_NS
+}
+
+// ---- host backend ---------------------------------------------------------------------------
+#define TRUSS_BACKEND_NAME "hip"
+struct truss_topo;
+static void *tb_dev_alloc(size_t n) {
+  void *p = nullptr;
+  return hipMalloc(&p, n) == hipSuccess ? p : nullptr;
+}
+static void tb_dev_free(void *p) { (void)hipFree(p); }
+static bool tb_dev_upload(void *dst, const void *src, size_t n) {
+  return hipMemcpy(dst, src, n, hipMemcpyHostToDevice) == hipSuccess;
+}
+static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *stream);
+static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream);
+
+#include "truss_host.h"
+
+static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)truss_obs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return tb_fail(TRUSS_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(truss_obs_kernel, dim3((unsigned)A.B), dim3(64), tb_obs_lds_bytes(t->N), (hipStream_t)stream, t->dev, A);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("obs kernel launch failed: ") + hipGetErrorString(e));
+  return TRUSS_OK;
+}
+
+template <int G, int RPL, int EPL>
+static int hip_run(const truss_topo *t, const StepArgsDev &A, hipStream_t st) {
+  static bool attr_set = false;
+  static size_t attr_bytes = 0;
+  auto kern = truss_step_kernel<G, RPL, EPL>;
+  if (!attr_set || t->lds_bytes > attr_bytes) {  // dynamic LDS beyond 64 KiB needs the opt-in
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return tb_fail(TRUSS_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    attr_set = true;
+    attr_bytes = 160 * 1024;
+  }
+  constexpr int EPB = 64 / G;
+  const unsigned grid = (unsigned)((A.B + EPB - 1) / EPB);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), t->lds_bytes, st, t->dev, A);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return TRUSS_OK;
+}
+
+static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *stream) {
+  const TbVariant &v = kVariants[t->variant];
+  hipStream_t st = (hipStream_t)stream;
+#define CASE(g, r, e) \
+  if (v.G == g && v.RPL == r && v.EPL == e) return hip_run<g, r, e>(t, A, st);
+  CASE(8, 1, 5) CASE(8, 1, 10) CASE(8, 2, 5) CASE(8, 2, 10) CASE(16, 1, 3) CASE(16, 1, 5)
+  CASE(4, 2, 10) CASE(4, 2, 20) CASE(4, 4, 20)
+#undef CASE
+  return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled");
+}

@@ -1,0 +1,523 @@
+// truss_host.h -- host side of the C ABI (include/truss_mi355.h): topology tables, DOF numbering,
+// band ordering, LDS layout, argument checking and kernel selection.  Header-only and backend
+// agnostic: the includer provides
+//     TRUSS_BACKEND_NAME                           "hip" | "emu"
+//     void *tb_dev_alloc(size_t);  void tb_dev_free(void *);
+//     bool tb_dev_upload(void *dst, const void *src, size_t bytes);
+//     int  tb_launch_step(const truss_topo *, const StepArgsDev &, void *stream);
+//     int  tb_launch_obs(const truss_topo *, const ObsArgsDev &, void *stream);
+// truss_hip.hip implements them with the HIP runtime; tests/emu/truss_emu.cpp with malloc and the
+// CPU lane emulator.
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "../../include/truss_mi355.h"
+
+static thread_local std::string g_truss_err;
+static int tb_fail(int code, const std::string &msg) {
+  g_truss_err = msg;
+  return code;
+}
+
+// compiled (G, RPL, EPL) instantiations of the step kernel; keep in sync with the dispatch tables
+struct TbVariant {
+  int G, RPL, EPL;
+};
+static const TbVariant kVariants[] = {
+    {8, 1, 5}, {8, 1, 10}, {8, 2, 5}, {8, 2, 10}, {16, 1, 3}, {16, 1, 5}, {4, 2, 10}, {4, 2, 20}, {4, 4, 20},
+};
+static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+
+static inline size_t tb_obs_lds_bytes(int N) {
+  return ((((size_t)(N * 13 + 26) * 4 + 15) & ~(size_t)15) + (size_t)3 * N * N * 4 + 15) & ~(size_t)15;
+}
+
+struct truss_topo {
+  int N = 0, E = 0, NP = 0, ndof = 0, n_pad = 0, n_rest = 0, bw = 0;
+  int G = 0, RPL = 0, EPL = 0, W = 0, variant = -1;
+  std::vector<int32_t> nsc, ttnsc, perm;
+  TopoDev dev{};
+  void *blob = nullptr;
+  size_t lds_bytes = 0;
+  int n_sections = 0;
+};
+
+// --- DOF numbering, FEM_2Dtruss.py:227-261 ---------------------------------------------------
+static void tb_dof_numbering(const uint8_t *res, int N, std::vector<int32_t> &nsc, int &ndof) {
+  nsc.assign(2 * N, 0);
+  int c = 1;
+  for (int i = 0; i < 2 * N; ++i)
+    if (res[i] == 0) nsc[i] = c++;
+  ndof = c - 1;
+  for (int i = 0; i < 2 * N; ++i)
+    if (res[i] != 0) nsc[i] = c++;
+}
+
+// half bandwidth (in DOFs) of K when nodes are visited in `order`
+static int tb_bandwidth(const std::vector<int> &order, const uint8_t *res, const int32_t *conn, int N, int E,
+                        std::vector<int> *dofpos_out) {
+  std::vector<int> pos(2 * N, -1);
+  int c = 0;
+  for (int i = 0; i < N; ++i) {
+    int n = order[i];
+    for (int k = 0; k < 2; ++k)
+      if (res[2 * n + k] == 0) pos[2 * n + k] = c++;
+  }
+  int bw = 0;
+  for (int n = 0; n < N; ++n)
+    if (pos[2 * n] >= 0 && pos[2 * n + 1] >= 0) bw = std::max(bw, std::abs(pos[2 * n] - pos[2 * n + 1]));
+  for (int e = 0; e < E; ++e) {
+    int a = conn[2 * e], b = conn[2 * e + 1];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) {
+        int pa = pos[2 * a + i], pb = pos[2 * b + j];
+        if (pa >= 0 && pb >= 0) bw = std::max(bw, std::abs(pa - pb));
+      }
+  }
+  if (dofpos_out) *dofpos_out = pos;
+  return bw;
+}
+
+// reverse Cuthill-McKee from `start` on the node graph
+static std::vector<int> tb_rcm(int start, const std::vector<std::vector<int>> &adj, int N) {
+  std::vector<int> order;
+  std::vector<char> seen(N, 0);
+  auto bfs = [&](int s) {
+    std::queue<int> q;
+    q.push(s);
+    seen[s] = 1;
+    while (!q.empty()) {
+      int u = q.front();
+      q.pop();
+      order.push_back(u);
+      std::vector<int> nb;
+      for (int v : adj[u])
+        if (!seen[v]) {
+          seen[v] = 1;
+          nb.push_back(v);
+        }
+      std::sort(nb.begin(), nb.end(), [&](int a, int b) {
+        return adj[a].size() != adj[b].size() ? adj[a].size() < adj[b].size() : a < b;
+      });
+      for (int v : nb) q.push(v);
+    }
+  };
+  bfs(start);
+  for (int i = 0; i < N; ++i)
+    if (!seen[i]) bfs(i);
+  std::reverse(order.begin(), order.end());
+  return order;
+}
+
+static int tb_env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+template <typename T>
+static size_t tb_push(std::vector<char> &blob, const std::vector<T> &v) {
+  size_t off = (blob.size() + 15) & ~size_t(15);
+  blob.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+  return off;
+}
+
+extern "C" int truss_abi_version(void) { return TRUSS_ABI_VERSION; }
+extern "C" const char *truss_last_error(void) { return g_truss_err.c_str(); }
+extern "C" const char *truss_backend(void) { return TRUSS_BACKEND_NAME; }
+
+extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const int32_t *conn, const uint8_t *res,
+                                 const uint8_t *top, const int32_t *pair, const uint8_t *load_mask,
+                                 int32_t n_sym_nodes, const int32_t *sym_nodes, int32_t n_sym_elems,
+                                 const int32_t *sym_elems, int32_t n_sections, const double *sections, double e_mod,
+                                 double long_stress, const int32_t *node_order) {
+  if (!out || !conn || !res || !top || !sections) return tb_fail(TRUSS_EINVAL, "NULL argument");
+  if (N < 2 || E < 1 || N > 16000) return tb_fail(TRUSS_EINVAL, "bad N/E");
+  if (n_sections < 1) return tb_fail(TRUSS_EINVAL, "need at least one section");
+  if ((n_sym_nodes > 0 && !sym_nodes) || (n_sym_elems > 0 && !sym_elems)) return tb_fail(TRUSS_EINVAL, "sym table NULL");
+  for (int e = 0; e < E; ++e)
+    if (conn[2 * e] < 0 || conn[2 * e] >= N || conn[2 * e + 1] < 0 || conn[2 * e + 1] >= N || conn[2 * e] == conn[2 * e + 1])
+      return tb_fail(TRUSS_EINVAL, "conn out of range");
+  for (int i = 0; i < n_sym_nodes * 2; ++i)
+    if (sym_nodes[i] < 0 || sym_nodes[i] >= N) return tb_fail(TRUSS_EINVAL, "sym_nodes out of range");
+  for (int i = 0; i < n_sym_elems * 2; ++i)
+    if (sym_elems[i] < 0 || sym_elems[i] >= E) return tb_fail(TRUSS_EINVAL, "sym_elems out of range");
+
+  truss_topo *t = new truss_topo();
+  t->N = N;
+  t->E = E;
+  t->n_sections = n_sections;
+  tb_dof_numbering(res, N, t->nsc, t->ndof);
+  if (t->ndof < 1) {
+    delete t;
+    return tb_fail(TRUSS_EINVAL, "no free DOF");
+  }
+  t->n_rest = 2 * N - t->ndof;
+  t->ttnsc.resize(4 * E);
+  for (int e = 0; e < E; ++e) {  // FEM_2Dtruss.py:311-317
+    int a = conn[2 * e], b = conn[2 * e + 1];
+    t->ttnsc[4 * e + 0] = t->nsc[2 * a];
+    t->ttnsc[4 * e + 1] = t->nsc[2 * a + 1];
+    t->ttnsc[4 * e + 2] = t->nsc[2 * b];
+    t->ttnsc[4 * e + 3] = t->nsc[2 * b + 1];
+  }
+  // vertical pairs
+  std::vector<int16_t> pairs;
+  if (pair) {
+    for (int i = 0; i < N; ++i) {
+      int j = pair[i];
+      if (j < 0 || j >= N || j == i || pair[j] != i) {
+        delete t;
+        return tb_fail(TRUSS_EINVAL, "pair[] must be an involution without fixed points");
+      }
+      if (i < j) {
+        pairs.push_back((int16_t)i);
+        pairs.push_back((int16_t)j);
+      }
+    }
+  }
+  t->NP = (int)pairs.size() / 2;
+
+  // ---- node ordering for the banded solver: hint, natural, RCM from every start ----
+  std::vector<std::vector<int>> adj(N);
+  for (int e = 0; e < E; ++e) {
+    adj[conn[2 * e]].push_back(conn[2 * e + 1]);
+    adj[conn[2 * e + 1]].push_back(conn[2 * e]);
+  }
+  std::vector<std::vector<int>> cands;
+  if (node_order) {
+    std::vector<int> o(node_order, node_order + N);
+    std::vector<char> seen(N, 0);
+    bool ok = true;
+    for (int v : o) {
+      if (v < 0 || v >= N || seen[v]) ok = false;
+      else seen[v] = 1;
+    }
+    if (!ok) {
+      delete t;
+      return tb_fail(TRUSS_EINVAL, "node_order is not a permutation");
+    }
+    cands.push_back(o);
+  }
+  {
+    std::vector<int> nat(N);
+    for (int i = 0; i < N; ++i) nat[i] = i;
+    cands.push_back(nat);
+  }
+  for (int s = 0; s < N && N <= 1024; ++s) cands.push_back(tb_rcm(s, adj, N));
+  int best = -1, best_bw = 1 << 30;
+  for (size_t i = 0; i < cands.size(); ++i) {
+    int bw = tb_bandwidth(cands[i], res, conn, N, E, nullptr);
+    if (bw < best_bw) {
+      best_bw = bw;
+      best = (int)i;
+    }
+  }
+  std::vector<int> dofpos;
+  t->bw = tb_bandwidth(cands[best], res, conn, N, E, &dofpos);
+
+  // ---- kernel variant: smallest window that holds the band; TRUSS_LANES / TRUSS_RPL override ----
+  int want_G = tb_env_int("TRUSS_LANES", 0), want_RPL = tb_env_int("TRUSS_RPL", 0);
+  int pick = -1;
+  auto score = [&](const TbVariant &v) {
+    // default preference: 8 lanes for narrow bands, 16 lanes for wide ones, then smaller windows
+    int W = v.G * v.RPL;
+    int pref = (W == 8 && v.G == 8) ? 0 : (W == 16 && v.G == 16) ? 1 : (v.G == 8) ? 2 : 3;
+    return W * 1000 + pref * 100 + v.EPL;
+  };
+  for (int i = 0; i < kNumVariants; ++i) {
+    const TbVariant &v = kVariants[i];
+    int W = v.G * v.RPL;
+    if (W <= t->bw) continue;
+    if ((E + v.G - 1) / v.G > v.EPL) continue;
+    if (want_G && v.G != want_G) continue;
+    if (want_RPL && v.RPL != want_RPL) continue;
+    if (pick < 0 || score(v) < score(kVariants[pick])) pick = i;
+  }
+  if (pick < 0) {
+    char buf[256];
+    snprintf(buf, sizeof buf,
+             "no compiled kernel for half-bandwidth %d with %d elements (windows: 8, 16; lanes 4/8/16)", t->bw, E);
+    delete t;
+    return tb_fail(TRUSS_EUNSUPPORTED, buf);
+  }
+  t->variant = pick;
+  t->G = kVariants[pick].G;
+  t->RPL = kVariants[pick].RPL;
+  t->EPL = kVariants[pick].EPL;
+  t->W = t->G * t->RPL;
+  const int W = t->W;
+  t->n_pad = ((t->ndof + W - 1) / W) * W;
+
+  // solver position -> reference DOF (0-based) and node*2+comp
+  t->perm.assign(t->ndof, -1);
+  std::vector<int16_t> posnode(t->n_pad, -1), dofpos16(2 * N, -1), restslot(2 * N, -1);
+  for (int i = 0; i < 2 * N; ++i) {
+    if (dofpos[i] >= 0) {
+      t->perm[dofpos[i]] = t->nsc[i] - 1;
+      posnode[dofpos[i]] = (int16_t)i;
+      dofpos16[i] = (int16_t)dofpos[i];
+    } else {
+      restslot[i] = (int16_t)(t->nsc[i] - t->ndof - 1);
+    }
+  }
+  // assembly codes (FEM_2Dtruss.py:320-324 restricted to the lower band)
+  std::vector<int32_t> asm_code(10 * (size_t)E, -1);
+  bool band_ok = true;
+  for (int e = 0; e < E; ++e) {
+    int a = conn[2 * e], b = conn[2 * e + 1];
+    int pa[2] = {dofpos[2 * a], dofpos[2 * a + 1]}, pb[2] = {dofpos[2 * b], dofpos[2 * b + 1]};
+    int n = 0;
+    auto add = [&](int r, int c, int type, int neg) {
+      int32_t code = -1;
+      if (r >= 0 && c >= 0) {
+        if (r < c) std::swap(r, c);
+        if (r - c >= W) band_ok = false;
+        code = ((r * W + (r - c)) << 3) | (type << 1) | neg;
+      }
+      asm_code[10 * (size_t)e + n++] = code;
+    };
+    add(pa[0], pa[0], 0, 0);
+    add(pa[1], pa[1], 2, 0);
+    add(pa[0], pa[1], 1, 0);
+    add(pb[0], pb[0], 0, 0);
+    add(pb[1], pb[1], 2, 0);
+    add(pb[0], pb[1], 1, 0);
+    add(pa[0], pb[0], 0, 1);
+    add(pa[1], pb[1], 2, 1);
+    add(pa[0], pb[1], 1, 1);
+    add(pa[1], pb[0], 1, 1);
+  }
+  if (!band_ok) {
+    delete t;
+    return tb_fail(TRUSS_EUNSUPPORTED, "internal: band wider than window");
+  }
+  std::vector<int16_t> conn16(2 * (size_t)E);
+  for (int i = 0; i < 2 * E; ++i) conn16[i] = (int16_t)conn[i];
+  std::vector<uint8_t> nflags(N, 0);
+  for (int n = 0; n < N; ++n) {
+    uint8_t f = 0;
+    if (top[n]) f |= TF_TOP;
+    if (res[2 * n]) f |= TF_RESX;
+    if (res[2 * n + 1]) f |= TF_RESY;
+    bool lb, lr;
+    if (load_mask) {
+      lb = load_mask[n] != 0;
+      lr = load_mask[N + n] != 0;
+    } else {  // truss2D_GEN.py:421-430
+      lb = !top[n] && res[2 * n + 1] == 0;
+      lr = top[n] != 0;
+    }
+    if (lb) f |= TF_LOAD_BRIDGE;
+    if (lr) f |= TF_LOAD_ROOF;
+    nflags[n] = f;
+  }
+  std::vector<int16_t> symn(2 * (size_t)n_sym_nodes), syme(2 * (size_t)n_sym_elems);
+  for (int i = 0; i < 2 * n_sym_nodes; ++i) symn[i] = (int16_t)sym_nodes[i];
+  for (int i = 0; i < 2 * n_sym_elems; ++i) syme[i] = (int16_t)sym_elems[i];
+  std::vector<double> area(n_sections);
+  for (int i = 0; i < n_sections; ++i) area[i] = sections[2 * i];
+
+  std::vector<char> blob;
+  size_t o_conn = tb_push(blob, conn16), o_pairs = tb_push(blob, pairs), o_nf = tb_push(blob, nflags);
+  size_t o_dp = tb_push(blob, dofpos16), o_rs = tb_push(blob, restslot), o_asm = tb_push(blob, asm_code);
+  size_t o_pn = tb_push(blob, posnode), o_sn = tb_push(blob, symn), o_se = tb_push(blob, syme);
+  size_t o_ar = tb_push(blob, area);
+  t->blob = tb_dev_alloc(blob.size());
+  if (!t->blob || !tb_dev_upload(t->blob, blob.data(), blob.size())) {
+    if (t->blob) tb_dev_free(t->blob);
+    delete t;
+    return tb_fail(TRUSS_ENOMEM, "device allocation/upload of topology tables failed");
+  }
+  char *base = (char *)t->blob;
+  TopoDev &D = t->dev;
+  D.N = N;
+  D.E = E;
+  D.NP = t->NP;
+  D.ndof = t->ndof;
+  D.n_pad = t->n_pad;
+  D.n_rest = t->n_rest;
+  D.n_sym_nodes = n_sym_nodes;
+  D.n_sym_elems = n_sym_elems;
+  D.n_sections = n_sections;
+  D.has_pairs = t->NP > 0 && 2 * t->NP == N;
+  D.conn = (const int16_t *)(base + o_conn);
+  D.pairs = (const int16_t *)(base + o_pairs);
+  D.nflags = (const uint8_t *)(base + o_nf);
+  D.dofpos = (const int16_t *)(base + o_dp);
+  D.restslot = (const int16_t *)(base + o_rs);
+  D.asm_code = (const int32_t *)(base + o_asm);
+  D.posnode = (const int16_t *)(base + o_pn);
+  D.sym_nodes = (const int16_t *)(base + o_sn);
+  D.sym_elems = (const int16_t *)(base + o_se);
+  D.sec_area = (const double *)(base + o_ar);
+  D.e_mod = e_mod;
+  D.long_stress = long_stress;
+  // LDS layout of one env (bytes, every array 16-byte aligned)
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off = (off + bytes + 15) & ~size_t(15);
+    return (int32_t)o;
+  };
+  D.o_kb = carve(sizeof(double) * (size_t)(t->n_pad + W) * W);
+  D.o_zs = carve(sizeof(double) * (t->n_pad + W));
+  D.o_dinv = carve(sizeof(double) * t->n_pad);
+  D.o_xsol = carve(sizeof(double) * (t->n_pad + 1));
+  D.o_red = carve(sizeof(double) * TRUSS_NRED * t->G);
+  D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
+  D.o_ysh = carve(sizeof(float) * N);
+  D.o_xsh = carve(sizeof(float) * N);
+  D.o_tac = carve(sizeof(float) * 3 * N);
+  D.o_sec = carve(sizeof(int32_t) * E);
+  // stagger env regions across LDS banks: stride = 64 B (mod 256 B)
+  size_t stride = (off + 255) & ~size_t(255);
+  stride += 64;
+  D.env_stride = (int32_t)stride;
+  t->lds_bytes = stride * (64 / t->G);
+  if (t->lds_bytes > 160 * 1024) {
+    tb_dev_free(t->blob);
+    delete t;
+    return tb_fail(TRUSS_EUNSUPPORTED, "topology needs more than 160 KiB of LDS per workgroup");
+  }
+  *out = t;
+  return TRUSS_OK;
+}
+
+extern "C" int truss_topo_destroy(truss_topo_t *t) {
+  if (!t) return TRUSS_OK;
+  if (t->blob) tb_dev_free(t->blob);
+  delete t;
+  return TRUSS_OK;
+}
+
+extern "C" int truss_topo_dofs(const truss_topo_t *t, int32_t *nsc, int32_t *ttnsc) {
+  if (!t) return tb_fail(TRUSS_EINVAL, "NULL topology");
+  if (nsc) memcpy(nsc, t->nsc.data(), t->nsc.size() * sizeof(int32_t));
+  if (ttnsc) memcpy(ttnsc, t->ttnsc.data(), t->ttnsc.size() * sizeof(int32_t));
+  return t->ndof;
+}
+
+extern "C" int truss_topo_solver_info(const truss_topo_t *t, int32_t *perm, int32_t *half_bandwidth,
+                                      int32_t *lanes_per_env, int32_t *rows_per_lane) {
+  if (!t) return tb_fail(TRUSS_EINVAL, "NULL topology");
+  if (perm) memcpy(perm, t->perm.data(), t->perm.size() * sizeof(int32_t));
+  if (half_bandwidth) *half_bandwidth = t->bw;
+  if (lanes_per_env) *lanes_per_env = t->G;
+  if (rows_per_lane) *rows_per_lane = t->RPL;
+  return TRUSS_OK;
+}
+
+static int tb_make_step_args(const truss_topo_t *t, const truss_step_args_t *a, StepArgsDev &D) {
+  if (!t || !a) return tb_fail(TRUSS_EINVAL, "NULL argument");
+  if (a->struct_size != sizeof(truss_step_args_t)) return tb_fail(TRUSS_EINVAL, "truss_step_args_t size mismatch (ABI)");
+  if (a->n_envs < 1) return tb_fail(TRUSS_EINVAL, "n_envs < 1");
+  const bool decode = !(a->flags & TRUSS_F_NO_DECODE);
+  if (!a->x || !a->y_in || !a->sec_in || !a->target || !a->env_params || !a->y_out || !a->disp || !a->q0 || !a->sr ||
+      !a->comp || !a->point)
+    return tb_fail(TRUSS_EINVAL, "a required device pointer is NULL");
+  if (decode && (!a->a_geo || !a->a_topo)) return tb_fail(TRUSS_EINVAL, "actions are NULL");
+  if (decode && !t->dev.has_pairs) return tb_fail(TRUSS_EINVAL, "action decode needs a vertical-pair table");
+  if ((a->max_up_in == nullptr) != (a->max_down_in == nullptr)) return tb_fail(TRUSS_EINVAL, "max_up_in/max_down_in must come together");
+  if ((a->max_up_out == nullptr) != (a->max_down_out == nullptr)) return tb_fail(TRUSS_EINVAL, "max_up_out/max_down_out must come together");
+  if (decode && t->dev.n_sym_nodes + t->dev.n_sym_elems > 0 && !a->coin) return tb_fail(TRUSS_EINVAL, "symmetric topology needs coin[]");
+  D.B = a->n_envs;
+  D.flags = a->flags;
+  D.x = a->x;
+  D.y_in = a->y_in;
+  D.sec_in = a->sec_in;
+  D.mu_in = a->max_up_in;
+  D.md_in = a->max_down_in;
+  D.a_geo = a->a_geo;
+  D.a_topo = a->a_topo;
+  D.coin = a->coin;
+  D.target = a->target;
+  D.env_params = a->env_params;
+  D.y_out = a->y_out;
+  D.sec_out = a->sec_out;
+  D.mu_out = a->max_up_out;
+  D.md_out = a->max_down_out;
+  D.disp = a->disp;
+  D.q0 = a->q0;
+  D.sr = a->sr;
+  D.comp = a->comp;
+  D.point = a->point;
+  D.obj = a->obj;
+  D.disp64 = a->disp_f64;
+  D.q064 = a->q0_f64;
+  D.energy = a->energy;
+  D.react = a->reactions;
+  D.status = a->status;
+  return TRUSS_OK;
+}
+
+extern "C" int truss_step(const truss_topo_t *t, const truss_step_args_t *a, void *stream) {
+  StepArgsDev D;
+  int rc = tb_make_step_args(t, a, D);
+  if (rc != TRUSS_OK) return rc;
+  return tb_launch_step(t, D, stream);
+}
+
+extern "C" int truss_rollout(const truss_topo_t *t, const truss_step_args_t *a, int32_t n_steps, int32_t n_action_sets,
+                             void *stream) {
+  StepArgsDev D;
+  int rc = tb_make_step_args(t, a, D);
+  if (rc != TRUSS_OK) return rc;
+  if (n_steps < 1 || n_action_sets < 1) return tb_fail(TRUSS_EINVAL, "n_steps/n_action_sets < 1");
+  if (!a->sec_out) return tb_fail(TRUSS_EINVAL, "rollout needs sec_out");
+  if (a->max_up_in) return tb_fail(TRUSS_EINVAL, "rollout recomputes move ranges; pass max_up_in = NULL");
+  const float *ybuf[2] = {a->y_in, a->y_out};
+  const int32_t *sbuf[2] = {a->sec_in, a->sec_out};
+  const size_t gstride = (size_t)a->n_envs * t->N * 2, tstride = (size_t)a->n_envs * t->N * 3;
+  for (int s = 0; s < n_steps; ++s) {
+    StepArgsDev S = D;
+    S.y_in = ybuf[s & 1];
+    S.y_out = (float *)ybuf[(s + 1) & 1];
+    S.sec_in = sbuf[s & 1];
+    S.sec_out = (int32_t *)sbuf[(s + 1) & 1];
+    if (D.a_geo) {
+      S.a_geo = D.a_geo + (size_t)(s % n_action_sets) * gstride;
+      S.a_topo = D.a_topo + (size_t)(s % n_action_sets) * tstride;
+    }
+    rc = tb_launch_step(t, S, stream);
+    if (rc != TRUSS_OK) return rc;
+  }
+  return TRUSS_OK;
+}
+
+extern "C" int truss_obs(const truss_topo_t *t, const truss_obs_args_t *a, void *stream) {
+  if (!t || !a) return tb_fail(TRUSS_EINVAL, "NULL argument");
+  if (a->struct_size != sizeof(truss_obs_args_t)) return tb_fail(TRUSS_EINVAL, "truss_obs_args_t size mismatch (ABI)");
+  if (a->n_envs < 1) return tb_fail(TRUSS_EINVAL, "n_envs < 1");
+  if (!a->x || !a->y || !a->sec || !a->max_up || !a->max_down || !a->target || !a->disp || !a->q0 || !a->sr || !a->comp ||
+      !a->env_params)
+    return tb_fail(TRUSS_EINVAL, "a required device pointer is NULL");
+  if (tb_obs_lds_bytes(t->N) > 160 * 1024) return tb_fail(TRUSS_EUNSUPPORTED, "N too large for the observation kernel");
+  ObsArgsDev D;
+  D.B = a->n_envs;
+  D.flags = a->flags;
+  D.x = a->x;
+  D.y = a->y;
+  D.sec = a->sec;
+  D.mu = a->max_up;
+  D.md = a->max_down;
+  D.target = a->target;
+  D.disp = a->disp;
+  D.q0 = a->q0;
+  D.sr = a->sr;
+  D.comp = a->comp;
+  D.env_params = a->env_params;
+  D.x_n = a->x_n;
+  D.A_s = a->A_s;
+  D.A_ts = a->A_n_ts;
+  D.A_cs = a->A_n_cs;
+  D.nxn = a->nN_x_n;
+  D.nxe = a->nN_x_e;
+  return tb_launch_obs(t, D, stream);
+}

@@ -1,0 +1,133 @@
+"""CPU tests of the kernel's lane program through the lane emulator (tests/emu), of the host logic
+and of the C ABI surface.  No GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import truss_mi355 as tm
+from truss_mi355 import synthetic
+from oracle import truss_oracle as O
+from conftest import ROOT, SCENARIOS
+import parity_common as pc
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return pc.emu_lib()
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_golden_transitions_emulated(lib, name):
+    pc.run_golden_transitions(lib, name)
+
+
+@pytest.mark.parametrize("num_x,n_extra,B,steps", [(16, 4, 19, 3), (16, 0, 8, 2), (6, 0, 5, 3)])
+def test_random_rollout_emulated(lib, num_x, n_extra, B, steps):
+    pc.run_random_rollout(lib, num_x, n_extra, B, steps, seed=11 + num_x)
+
+
+@pytest.mark.parametrize("name", ["train0", "small_roof", "large_bridge"])
+def test_observation_tensors_golden_emulated(lib, name):
+    pc.run_obs_golden(lib, name)
+
+
+def test_observation_tensors_random_emulated(lib):
+    pc.run_obs_random(lib, 16, 4, 7, seed=21)
+    pc.run_obs_random(lib, 6, 0, 3, seed=22)
+
+
+def test_symmetric_variants_random(lib):
+    pc.run_random_rollout(lib, 8, 0, 9, 2, seed=5, symmetry="small")
+    pc.run_random_rollout(lib, 16, 0, 6, 2, seed=6, symmetry="large")
+
+
+def test_threebar_analysis_only(lib):
+    f = np.load(os.path.join(pc.GOLDEN, "threebar.npz"))
+    topo = tm.TrussTopology(f["conn"], f["res"], np.zeros(4, np.uint8), pair=None,
+                            load_mask=np.array([[1, 0, 0, 0], [1, 0, 0, 0]]),
+                            sections=np.array([[8.0, 1.0], [6.0, 1.0]]), e_mod=float(f["em"]), long_stress=1.0)
+    nsc, tt, nd = topo.dofs(lib)
+    assert np.array_equal(nsc, f["nsc"]) and np.array_equal(tt, f["ttnsc"]) and nd == 2
+    env = tm.BatchedTruss(topo, 3, lib=lib, debug_f64=True)
+    env.set_constants(f["coords"][:, 0], np.zeros(4), 1e9, 0.0, 1.0, 150.0, -300.0, 0.0)
+    env.set_design(f["coords"][:, 1], np.array([0, 1, 0]))
+    env.analyze()
+    r = env.results()
+    for b in range(3):
+        assert pc.rel(r["q0_f64"][b], f["q0"]) < 1e-12
+        assert pc.rel(r["disp_f64"][b][0], f["d"]) < 1e-12
+        assert pc.rel(r["reactions"][b], f["r"][2:]) < 1e-12
+        assert pc.rel(r["energy"][b], f["U"]) < 1e-12
+    with pytest.raises(tm.TrussError):      # no pair table -> the action decode is refused, loudly
+        env.step(torch.zeros(3, 4, 2), torch.zeros(3, 4, 3))
+
+
+def test_rollout_matches_stepwise(lib):
+    topo = synthetic.bench_topology(16, 4)
+    batch = synthetic.random_batch(topo, 10, 3)
+    ag, at = synthetic.random_actions(3, 10, topo.N, 9)
+    e1 = pc.make_env(lib, topo, batch)
+    e1.analyze(set_normalisers=True)
+    e2 = pc.make_env(lib, topo, batch)
+    e2.analyze(set_normalisers=True)
+    for s in range(5):
+        e1.step(torch.tensor(ag[s % 3]), torch.tensor(at[s % 3]))
+    e2.rollout(torch.tensor(ag), torch.tensor(at), 5)
+    r1, r2 = e1.results(), e2.results()
+    for k in ("y", "sec", "point", "q0", "sr", "disp", "comp"):
+        assert np.array_equal(r1[k], r2[k]), k
+
+
+def test_singular_design_is_flagged(lib):
+    """A mechanism (zero-area is impossible, so: all nodes of a bay collapsed) must raise status."""
+    topo = tm.TrussTopology.grid(6)
+    batch = synthetic.random_batch(topo, 2, 1)
+    batch["y"][0, 6:] = 0.0          # top chord on the bottom chord: K singular for env 0
+    env = pc.make_env(lib, topo, batch)
+    env.analyze()
+    st = env.results()["status"]
+    assert st[0] == 1 and st[1] == 0
+
+
+def test_argument_errors(lib):
+    topo = tm.TrussTopology.grid(6)
+    env = tm.BatchedTruss(topo, 4, lib=lib)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(4, 12, 2, dtype=torch.float64), torch.zeros(4, 12, 3))
+    bad = tm.TrussTopology([[0, 1], [1, 2]], np.zeros((3, 2)), np.zeros(3), pair=[1, 0, 2])
+    with pytest.raises(tm.TrussError):
+        bad.native(lib)
+    # half-bandwidth beyond the compiled windows -> refused, not silently wrong
+    N = 40
+    conn = [(i, i + 1) for i in range(N - 1)] + [(7, j) for j in range(9, N)]   # free hub: no narrow band exists
+    res = np.zeros((N, 2)); res[0] = 1; res[3] = 1
+    wide = tm.TrussTopology(conn, res, np.zeros(N))
+    with pytest.raises(tm.TrussError):
+        wide.native(lib)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    """The product .so must load and export exactly what include/truss_mi355.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "truss_mi355.h")).read()
+    names = set(re.findall(r"\b(truss_[a-z_]+)\s*\(", hdr))
+    names = {n for n in names if not n.endswith("_t")}
+    assert {"truss_step", "truss_rollout", "truss_topo_create", "truss_obs"} <= names
+    path = tm._lib.DEFAULT_LIB
+    assert os.path.exists(path), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
+    dll = ctypes.CDLL(path)
+    for n in sorted(names):
+        assert hasattr(dll, n), n
+    dll.truss_backend.restype = ctypes.c_char_p
+    assert dll.truss_backend() == b"hip"
+    dll.truss_abi_version.restype = ctypes.c_int
+    assert dll.truss_abi_version() == 1
+
+
+def test_product_refuses_non_hip_default(monkeypatch, tmp_path):
+    missing = tmp_path / "nope.so"
+    with pytest.raises(tm.TrussError):
+        tm._lib.TrussLib(str(missing))

@@ -1,0 +1,154 @@
+"""GPU parity tests: the hand-written HIP path (through the C ABI) against the oracle and against
+the reference's golden vectors.  Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import truss_mi355 as tm
+from truss_mi355 import synthetic
+from oracle import truss_oracle as O
+from conftest import SCENARIOS
+import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    lib = tm.load()          # the in-tree HIP .so; raises if it is missing
+    assert lib.backend == "hip"
+    return lib
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_golden_transitions(lib, name):
+    pc.run_golden_transitions(lib, name)
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_observation_tensors_golden(lib, name):
+    pc.run_obs_golden(lib, name)
+
+
+@pytest.mark.parametrize("num_x,n_extra,B,steps", [(16, 4, 257, 4), (16, 0, 100, 3), (8, 0, 64, 3), (6, 0, 33, 3)])
+def test_random_rollout(lib, num_x, n_extra, B, steps):
+    pc.run_random_rollout(lib, num_x, n_extra, B, steps, seed=100 + num_x)
+
+
+def test_symmetric_variants_random(lib):
+    pc.run_random_rollout(lib, 8, 0, 50, 3, seed=5, symmetry="small")
+    pc.run_random_rollout(lib, 16, 0, 50, 3, seed=6, symmetry="large")
+
+
+def test_observation_tensors_random(lib):
+    pc.run_obs_random(lib, 16, 4, 129, seed=21)
+    pc.run_obs_random(lib, 6, 0, 17, seed=22)
+
+
+def test_full_size_properties(lib):
+    """BASELINE size (32 nodes / 80 elements / 4096 envs): size-independent properties.
+    (1) a random 256-env sample agrees with the oracle; (2) equilibrium: reactions balance the applied
+    load; (3) work-energy: U = 1/2 d.P; (4) determinism: two runs are bit-identical;
+    (5) linearity: doubling the load doubles displacements and member forces."""
+    topo = synthetic.bench_topology(16, 4)
+    B = 4096
+    batch = synthetic.random_batch(topo, B, 77)
+    env = pc.make_env(lib, topo, batch)
+    env.analyze(set_normalisers=True)
+    ag, at = synthetic.random_actions(2, B, topo.N, 78)
+    g0, t0 = torch.tensor(ag[0], device=env.device), torch.tensor(at[0], device=env.device)
+    env.step(g0, t0)
+    r1 = env.results()
+    assert int(r1["status"].sum()) == 0
+    # (1) oracle on a sample
+    idx = np.random.default_rng(0).choice(B, 256, replace=False)
+    ot = pc.oracle_topology(topo)
+    sub = {k: v[idx] for k, v in batch.items()}
+    int_obj = O.initial_objectives(ot, sub["x"], sub["y"], sub["sec"], sub["target"])
+    o = O.env_step(ot, sub["x"], sub["y"], sub["sec"], None, None, ag[0][idx], at[0][idx], np.zeros(256),
+                   sub["target"], pc.oracle_load(ot, sub), sub["y_max"], sub["d_min"], sub["max_def"], sub["is_roof"],
+                   int_obj)
+    pc.compare_step({k: v[idx] for k, v in r1.items()}, o, ot)
+    # (2) equilibrium
+    nloaded = np.where(batch["is_roof"] > 0, topo.load_mask[1].sum(), topo.load_mask[0].sum())
+    total = batch["load_y"] * nloaded
+    ry = r1["reactions"][:, 1] + r1["reactions"][:, 3]
+    rx = r1["reactions"][:, 0] + r1["reactions"][:, 2]
+    np.testing.assert_allclose(ry, -total, rtol=1e-8)
+    assert np.abs(rx).max() < 1e-6 * np.abs(total).max()
+    # (3) work = energy
+    P = np.zeros((B, topo.N))
+    for b in range(B):
+        P[b, topo.load_mask[1 if batch["is_roof"][b] else 0].astype(bool)] = batch["load_y"][b]
+    work = 0.5 * (P * r1["disp_f64"][:, :, 1]).sum(axis=1)
+    np.testing.assert_allclose(r1["energy"], work, rtol=1e-9)
+    # (4) determinism
+    env2 = pc.make_env(lib, topo, batch)
+    env2.analyze(set_normalisers=True)
+    env2.step(g0, t0)
+    r2 = env2.results()
+    for k in ("y", "sec", "point", "disp", "q0", "sr", "comp"):
+        assert np.array_equal(r1[k], r2[k]), k
+    # (5) linearity in the load
+    b2 = dict(batch)
+    b2["load_y"] = batch["load_y"] * 2.0
+    b2["y"], b2["sec"] = r1["y"], r1["sec"]
+    b1 = dict(batch)
+    b1["y"], b1["sec"] = r1["y"], r1["sec"]
+    ea, eb = pc.make_env(lib, topo, b1), pc.make_env(lib, topo, b2)
+    ea.analyze()
+    eb.analyze()
+    ra, rb = ea.results(), eb.results()
+    np.testing.assert_allclose(rb["disp_f64"], 2.0 * ra["disp_f64"], rtol=1e-9, atol=1e-18)
+    np.testing.assert_allclose(rb["q0_f64"], 2.0 * ra["q0_f64"], rtol=1e-8, atol=1e-6)
+
+
+def test_rollout_matches_stepwise(lib):
+    topo = synthetic.bench_topology(16, 4)
+    B = 1000
+    batch = synthetic.random_batch(topo, B, 3)
+    ag, at = synthetic.random_actions(3, B, topo.N, 9)
+    e1 = pc.make_env(lib, topo, batch)
+    e1.analyze(set_normalisers=True)
+    e2 = pc.make_env(lib, topo, batch)
+    e2.analyze(set_normalisers=True)
+    G, T = torch.tensor(ag, device=e1.device), torch.tensor(at, device=e1.device)
+    for s in range(7):
+        e1.step(G[s % 3], T[s % 3])
+    e2.rollout(G, T, 7)
+    r1, r2 = e1.results(), e2.results()
+    for k in ("y", "sec", "point", "q0", "sr", "disp", "comp"):
+        assert np.array_equal(r1[k], r2[k]), k
+
+
+def test_every_kernel_variant(lib, monkeypatch):
+    """Each compiled lanes-per-env x rows-per-lane instantiation gives the same answers."""
+    for G, RPL in [(8, 1), (16, 1), (4, 2), (8, 2)]:
+        monkeypatch.setenv("TRUSS_LANES", str(G))
+        monkeypatch.setenv("TRUSS_RPL", str(RPL))
+        topo = tm.TrussTopology.grid(16)
+        info = topo.solver_info(lib)
+        assert (info["lanes_per_env"], info["rows_per_lane"]) == (G, RPL)
+        batch = synthetic.random_batch(topo, 70, 31)
+        env = pc.make_env(lib, topo, batch)
+        env.analyze(set_normalisers=True)
+        ot = pc.oracle_topology(topo)
+        int_obj = O.initial_objectives(ot, batch["x"], batch["y"], batch["sec"], batch["target"])
+        ag, at = synthetic.random_actions(1, 70, topo.N, 32)
+        env.step(torch.tensor(ag[0], device=env.device), torch.tensor(at[0], device=env.device))
+        o = O.env_step(ot, batch["x"], batch["y"], batch["sec"], None, None, ag[0], at[0], np.zeros(70),
+                       batch["target"], pc.oracle_load(ot, batch), batch["y_max"], batch["d_min"], batch["max_def"],
+                       batch["is_roof"], int_obj)
+        pc.compare_step(env.results(), o, ot)
+        topo.close()
+
+
+def test_singular_design_is_flagged(lib):
+    topo = tm.TrussTopology.grid(6)
+    batch = synthetic.random_batch(topo, 2, 1)
+    batch["y"][0, 6:] = 0.0
+    env = pc.make_env(lib, topo, batch)
+    env.analyze()
+    st = env.results()["status"]
+    assert st[0] == 1 and st[1] == 0
