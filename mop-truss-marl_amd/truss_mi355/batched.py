@@ -37,6 +37,8 @@ class BatchedTruss:
         if device is None:
             device = "cuda" if self.lib.backend == "hip" else "cpu"
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if self.lib.backend == "hip" and self.device.type != "cuda":
             raise _lib.TrussError("the HIP library needs tensors on a cuda (ROCm) device")
         self.topo = topo
