@@ -15,6 +15,12 @@
 //   post        gen_v/gen_u/gen_q/gen_f/gen_r/gen_yield    FEM_2Dtruss.py:341-431
 //   objectives  _game_modify epilogue                      truss2D_ENV.py:503-525
 //
+// Data movement: phase_stage copies (a) the topology tables (one contiguous blob, a few KB, shared by
+// all envs of the workgroup) and (b) every per-env input row (heights, x, sections, actions, targets,
+// parameters) from HBM into LDS with 16-byte loads issued back to back, so a wave that sits alone on
+// its SIMD pays the HBM latency once instead of once per dependent table lookup.  Everything after
+// that reads LDS.
+//
 // Solver: K is SPD and banded once nodes are ordered along the span.  Free DOFs are permuted on the
 // host (truss_host.h) to solver positions 0..n-1 with half bandwidth < W = G*RPL.  Each lane keeps
 // RPL rows of the sliding W x W window of the partially factorised matrix in registers (row r lives
@@ -43,22 +49,38 @@
 #define TB_NO_DECODE 0x1u
 #define TB_CLAMP_INPLACE 0x2u
 
+struct alignas(16) tb_u4 {
+  uint32_t a, b, c, d;
+};
+
+// All topology tables live in ONE blob (global memory); f_* are byte offsets into it.  The step
+// kernel copies the blob to the start of its LDS and reads the copy; the observation kernel reads
+// the global blob directly.
 struct TopoDev {
   int32_t N, E, NP, ndof, n_pad, n_rest, n_sym_nodes, n_sym_elems, n_sections, has_pairs;
-  const int16_t *conn;       // [E][2]
-  const int16_t *pairs;      // [NP][2]  (lo, hi) with lo < hi
-  const uint8_t *nflags;     // [N]
-  const int16_t *dofpos;     // [N][2]   solver position of (node, comp) or -1 when restrained
-  const int16_t *restslot;   // [N][2]   reaction slot (reference order nsc-ndof-1) or -1
-  const int32_t *asm_code;   // [E][10]  (band offset << 3) | (type << 1) | negate, or -1
-  const int16_t *posnode;    // [n_pad]  node*2+comp at solver position, -1 = padding row
-  const int16_t *sym_nodes;  // [n][2]   (dst, src)
-  const int16_t *sym_elems;  // [n][2]
-  const double *sec_area;   // [n_sections] area in m^2
+  const char *blob;
+  int32_t blob_bytes;  // multiple of 16
+  int32_t f_conn;      // int16 [E][2]
+  int32_t f_pairs;     // int16 [NP][2]  (lo, hi) with lo < hi
+  int32_t f_nflags;    // uint8 [N]
+  int32_t f_dofpos;    // int16 [N][2]   solver position of (node, comp) or -1 when restrained
+  int32_t f_restslot;  // int16 [N][2]   reaction slot (reference order nsc-ndof-1) or -1
+  int32_t f_asm;       // int32 [E][10]  (band offset << 3) | (type << 1) | negate, or -1
+  int32_t f_posnode;   // int16 [n_pad]  node*2+comp at solver position, -1 = padding row
+  int32_t f_symn;      // int16 [n][2]   (dst, src)
+  int32_t f_syme;      // int16 [n][2]
+  int32_t f_area;      // double [n_sections] area in m^2
+  int32_t f_isr;       // double [n_sections] 1 / (area * long_stress)
+  int32_t f_adj8;      // int16 [N][8]   elements incident to each node, padded with E (a zero slot)
   double e_mod, long_stress;
-  // byte offsets inside one env's LDS region
-  int32_t o_kb, o_zs, o_dinv, o_xsol, o_red, o_rbuf, o_ysh, o_xsh, o_tac, o_sec, env_stride;
+  // LDS layout of the step kernel: [blob copy][env 0][env 1]...; o_* are byte offsets inside one env
+  int32_t o_env0, env_stride;
+  int32_t o_kb, o_zs, o_dinv, o_xsol, o_red, o_rbuf, o_par, o_y, o_x, o_tg, o_geo, o_tac, o_sec, o_ev, o_zring;
+  // output staging rows inside the (dead) band region, each 16-byte aligned
+  int32_t so_q0, so_sr, so_disp, so_mu, so_md, so_comp;
 };
+
+#define TB_TAB(type, base, off) ((const type *)((base) + (off)))
 
 struct StepArgsDev {
   int32_t B;
@@ -87,21 +109,25 @@ TRUSS_HD float tb_clamp01(float v) { return v > 1.0f ? 1.0f : (v < 0.0f ? 0.0f :
 // Python round(np.float32, 2): rint(v*100)/100 in float32 (truss2D_ENV.py:413)
 TRUSS_HD float tb_round2(float v) { return rintf(v * 100.0f) / 100.0f; }
 
-template <int G, int RPL, int EPL>
+// G lanes own one env; the solver window is WL lanes x RPL rows (W = WL*RPL columns).  When G > WL the
+// extra lanes mirror lane g % WL through the solver (same registers, same LDS addresses) and only
+// contribute in the per-node / per-element phases.
+template <int G, int WL, int RPL, int EPL>
 struct StepLane {
-  static constexpr int W = G * RPL;
+  static constexpr int W = WL * RPL;
   static constexpr int EPB = 64 / G;  // envs per wave
+  static constexpr int NDEG = 8;      // unrolled node-degree bound of the diagonal gather
 
-  int lane, g, env, envc;
+  int lane, g, gs, env, envc;
   bool active;
-  char *L;  // this env's LDS region
+  const char *TB;  // LDS copy of the topology blob
+  char *L;         // this env's LDS region
   // per-env scalars
   double max_def, load_x, load_y;
   float ymax32, dmin32, ymd32, int1, int2;
   int is_roof, heads;
   // element stash
-  double ek[EPL], ec[EPL], es[EPL], eA[EPL];
-  int esec[EPL];
+  double ek[EPL], ec[EPL], es[EPL], ei[EPL];
   // solver window
   double R[RPL][W];
   double rhs[RPL];
@@ -117,21 +143,147 @@ struct StepLane {
   TRUSS_HD double *xsol(const TopoDev &T) { return (double *)(L + T.o_xsol); }
   TRUSS_HD double *red(const TopoDev &T) { return (double *)(L + T.o_red); }
   TRUSS_HD double *rbuf(const TopoDev &T) { return (double *)(L + T.o_rbuf); }
-  TRUSS_HD float *ysh(const TopoDev &T) { return (float *)(L + T.o_ysh); }
-  TRUSS_HD float *xsh(const TopoDev &T) { return (float *)(L + T.o_xsh); }
+  TRUSS_HD double *zring(const TopoDev &T) { return (double *)(L + T.o_zring); }
+  TRUSS_HD double *par(const TopoDev &T) { return (double *)(L + T.o_par); }
+  TRUSS_HD float *ysh(const TopoDev &T) { return (float *)(L + T.o_y); }
+  TRUSS_HD float *xsh(const TopoDev &T) { return (float *)(L + T.o_x); }
+  TRUSS_HD float *tgsh(const TopoDev &T) { return (float *)(L + T.o_tg); }
+  TRUSS_HD float *geosh(const TopoDev &T) { return (float *)(L + T.o_geo); }
   TRUSS_HD float *tac(const TopoDev &T) { return (float *)(L + T.o_tac); }
   TRUSS_HD int32_t *secsh(const TopoDev &T) { return (int32_t *)(L + T.o_sec); }
+  TRUSS_HD double *evsh(const TopoDev &T) { return (double *)(L + T.o_ev); }
+  TRUSS_HD const int16_t *t_conn(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_conn); }
+  TRUSS_HD const int16_t *t_pairs(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_pairs); }
+  TRUSS_HD const uint8_t *t_nflags(const TopoDev &T) const { return TB_TAB(uint8_t, TB, T.f_nflags); }
+  TRUSS_HD const int16_t *t_dofpos(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_dofpos); }
+  TRUSS_HD const int16_t *t_restslot(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_restslot); }
+  TRUSS_HD const int32_t *t_asm(const TopoDev &T) const { return TB_TAB(int32_t, TB, T.f_asm); }
+  TRUSS_HD const int16_t *t_posnode(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_posnode); }
+  TRUSS_HD const int16_t *t_symn(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_symn); }
+  TRUSS_HD const int16_t *t_syme(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_syme); }
+  TRUSS_HD const double *t_area(const TopoDev &T) const { return TB_TAB(double, TB, T.f_area); }
+  TRUSS_HD const double *t_isr(const TopoDev &T) const { return TB_TAB(double, TB, T.f_isr); }
+  TRUSS_HD const int16_t *t_adj8(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_adj8); }
 
   // ------------------------------------------------------------------------------------------
   TRUSS_HD void init(int lane_, int block, const TopoDev &T, const StepArgsDev &A, char *lds) {
     lane = lane_;
     g = lane % G;
+    gs = g % WL;
     int grp = lane / G;
     env = block * EPB + grp;
     active = env < A.B;
     envc = active ? env : A.B - 1;
-    L = lds + (size_t)grp * T.env_stride;
-    const double *P = A.env_params + (size_t)envc * 8;
+    TB = lds;
+    L = lds + T.o_env0 + (size_t)grp * T.env_stride;
+    bad = 0;
+    p_vol = p_dt = p_en = 0.0;
+    p_c1 = p_c2 = 0.0f;
+  }
+
+  // ---- phase 0: HBM -> LDS (tables + this env's inputs), clear the band ------------------------
+  // A wave sits alone on its SIMD, so the HBM latency is paid once only if every load is in flight
+  // before the first dependent LDS store: all loads go to registers first (clamped indices, no
+  // control flow), then all stores.  Rows whose length is not a multiple of 4 words, or topologies
+  // beyond the unrolled bounds, take the plain loop (stage_row_slow).
+  static constexpr int BIT = 8;                                // blob units (16 B) per lane, unrolled
+  static constexpr int NIT = (64 / 4 + G - 1) / G;             // N <= 64: float4 units of an [N] row per lane
+  static constexpr int EIT = (128 / 4 + G - 1) / G;            // E <= 128
+
+  TRUSS_HD void stage_row_slow(const void *src, void *dst, int nwords) const {
+    const uint32_t *s1 = (const uint32_t *)src;
+    uint32_t *d1 = (uint32_t *)dst;
+    for (int q = g; q < nwords; q += G) d1[q] = s1[q];
+  }
+
+  template <int IT>
+  TRUSS_HD void row_load(const void *src, int nq, tb_u4 (&v)[IT]) const {
+    const tb_u4 *s4 = (const tb_u4 *)src;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int q = g + G * i;
+      v[i] = s4[q < nq ? q : nq - 1];
+    }
+  }
+  template <int IT>
+  TRUSS_HD void row_store(void *dst, int nq, const tb_u4 (&v)[IT]) const {
+    tb_u4 *d4 = (tb_u4 *)dst;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int q = g + G * i;
+      d4[q < nq ? q : nq - 1] = v[i];  // clamped like the load: a duplicate writes the same value; no
+    }                                  // branch, so the compiler cannot sink the load under a guard
+  }
+
+  TRUSS_HD void phase_stage(const TopoDev &T, const StepArgsDev &A) {
+    const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
+    const bool decode = !(A.flags & TB_NO_DECODE);
+    const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= 64 && T.E <= 128 && T.blob_bytes <= BIT * 64 * 16;
+    heads = A.coin ? (A.coin[envc] != 0) : 0;
+    if (fast) {
+      const int nb = T.blob_bytes >> 4, nn = T.N >> 2, ne = T.E >> 2;
+      tb_u4 vb[BIT], vy[NIT], vx[NIT], vt[NIT], vs[EIT], vp[1], vg[2 * NIT], va[3 * NIT];
+      {
+        const tb_u4 *s4 = (const tb_u4 *)T.blob;
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+          int q = lane + 64 * i;
+          vb[i] = s4[q < nb ? q : nb - 1];
+        }
+      }
+      row_load<NIT>(A.y_in + bn, nn, vy);
+      row_load<NIT>(A.x + bn, nn, vx);
+      row_load<NIT>(A.target + bn, nn, vt);
+      row_load<EIT>(A.sec_in + be, ne, vs);
+      row_load<1>(A.env_params + (size_t)envc * 8, 4, vp);
+      if (decode) {
+        row_load<2 * NIT>(A.a_geo + bn * 2, 2 * nn, vg);
+        row_load<3 * NIT>(A.a_topo + bn * 3, 3 * nn, va);
+      }
+      {
+        tb_u4 *d4 = (tb_u4 *)TB;
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+          int q = lane + 64 * i;
+          d4[q < nb ? q : nb - 1] = vb[i];
+        }
+      }
+      row_store<NIT>(ysh(T), nn, vy);
+      row_store<NIT>(xsh(T), nn, vx);
+      row_store<NIT>(tgsh(T), nn, vt);
+      row_store<EIT>(secsh(T), ne, vs);
+      row_store<1>(par(T), 4, vp);
+      if (decode) {
+        row_store<2 * NIT>(geosh(T), 2 * nn, vg);
+        row_store<3 * NIT>(tac(T), 3 * nn, va);
+      }
+    } else {
+      {
+        const tb_u4 *s4 = (const tb_u4 *)T.blob;
+        tb_u4 *d4 = (tb_u4 *)TB;
+        for (int q = lane; q < (T.blob_bytes >> 4); q += 64) d4[q] = s4[q];
+      }
+      stage_row_slow(A.y_in + bn, ysh(T), T.N);
+      stage_row_slow(A.x + bn, xsh(T), T.N);
+      stage_row_slow(A.target + bn, tgsh(T), T.N);
+      stage_row_slow(A.sec_in + be, secsh(T), T.E);
+      stage_row_slow(A.env_params + (size_t)envc * 8, par(T), 16);
+      if (decode) {
+        stage_row_slow(A.a_geo + bn * 2, geosh(T), 2 * T.N);
+        stage_row_slow(A.a_topo + bn * 3, tac(T), 3 * T.N);
+      }
+    }
+    // clear the band with 16-byte stores (padding-row identity is written after the next barrier)
+    {
+      tb_u4 *K4 = (tb_u4 *)kb(T);
+      const tb_u4 z = {0u, 0u, 0u, 0u};
+      const int tot4 = ((T.n_pad + W) * W) >> 1;
+      for (int i = g; i < tot4; i += G) K4[i] = z;
+    }
+  }
+
+  TRUSS_HD void load_params(const TopoDev &T) {
+    const double *P = par(T);
     double y_max = P[0], d_min = P[1];
     max_def = P[2];
     load_x = P[3];
@@ -142,24 +294,14 @@ struct StepLane {
     ymax32 = (float)y_max;
     dmin32 = (float)d_min;
     ymd32 = (float)(y_max - d_min);  // python float arithmetic, stored to float32 (ENV:482)
-    heads = A.coin ? (A.coin[envc] != 0) : 0;
-    bad = 0;
-    p_vol = p_dt = p_en = 0.0;
-    p_c1 = p_c2 = 0.0f;
   }
 
   // set_moveRange for one node (truss2D_GEN.py:118-133), float32
   TRUSS_HD void move_range(bool top, float y, float yp, float &up, float &dn) const {
-    if (top) {
-      up = fabsf(ymax32 - y);
-      dn = fabsf((y - yp) - dmin32);
-    } else if (is_roof) {
-      up = fabsf((yp - y) - dmin32);
-      dn = fabsf(y);
-    } else {
-      up = 0.0f;
-      dn = 0.0f;
-    }
+    float upt = fabsf(ymax32 - y), dnt = fabsf((y - yp) - dmin32);
+    float upb = is_roof ? fabsf((yp - y) - dmin32) : 0.0f, dnb = is_roof ? fabsf(y) : 0.0f;
+    up = top ? upt : upb;
+    dn = top ? dnt : dnb;
   }
 
   // geometry move + support + round for one node (truss2D_ENV.py:398-413)
@@ -173,149 +315,128 @@ struct StepLane {
     return resy ? 0.0f : y;
   }
 
-  // ---- phase 1: action decode for the lane's node pairs, stage y/x/actions in LDS, clear K ----
+  // ---- phase 1: action decode for the lane's node pairs (all operands in LDS) ----
   TRUSS_HD void phase_decode(const TopoDev &T, const StepArgsDev &A) {
+    load_params(T);
+    if (A.flags & TB_NO_DECODE) return;
     const size_t bn = (size_t)envc * T.N;
-    float *Y = ysh(T), *X = xsh(T), *TA = tac(T);
-    const bool decode = !(A.flags & TB_NO_DECODE);
-    if (decode) {
-      for (int p = g; p < T.NP; p += G) {
-        int nd[2] = {T.pairs[2 * p], T.pairs[2 * p + 1]};
-        float yv[2], mu[2], md[2], g0[2], g1[2];
-        bool top[2], resy[2];
-        for (int q = 0; q < 2; ++q) {
-          int n = nd[q];
-          yv[q] = A.y_in[bn + n];
-          top[q] = T.nflags[n] & TF_TOP;
-          resy[q] = T.nflags[n] & TF_RESY;
-          g0[q] = tb_clamp01(A.a_geo[(bn + n) * 2 + 0]);
-          g1[q] = tb_clamp01(A.a_geo[(bn + n) * 2 + 1]);
-          float t0 = tb_clamp01(A.a_topo[(bn + n) * 3 + 0]);
-          float t1 = tb_clamp01(A.a_topo[(bn + n) * 3 + 1]);
-          float t2 = tb_clamp01(A.a_topo[(bn + n) * 3 + 2]);
-          TA[n * 3 + 0] = t0;
-          TA[n * 3 + 1] = t1;
-          TA[n * 3 + 2] = t2;
-          if ((A.flags & TB_CLAMP_INPLACE) && active) {
-            A.a_geo[(bn + n) * 2 + 0] = g0[q];
-            A.a_geo[(bn + n) * 2 + 1] = g1[q];
-            A.a_topo[(bn + n) * 3 + 0] = t0;
-            A.a_topo[(bn + n) * 3 + 1] = t1;
-            A.a_topo[(bn + n) * 3 + 2] = t2;
-          }
-          X[n] = A.x[bn + n];
-        }
-        if (A.mu_in) {
-          for (int q = 0; q < 2; ++q) {
-            mu[q] = A.mu_in[bn + nd[q]];
-            md[q] = A.md_in[bn + nd[q]];
-          }
-        } else {
-          move_range(top[0], yv[0], yv[1], mu[0], md[0]);
-          move_range(top[1], yv[1], yv[0], mu[1], md[1]);
-        }
-        float a = move_node(yv[0], g0[0], g1[0], mu[0], md[0], resy[0]);
-        float b = move_node(yv[1], g0[1], g1[1], mu[1], md[1], resy[1]);
-        // sequential repairs (truss2D_ENV.py:469-490): visit lo then hi in each of the three loops
-        // loop 1: below y_min (= 0)
-        if (a < 0.0f) {
-          if (top[0]) { a = dmin32; b = 0.0f; } else { a = 0.0f; }
-        }
-        if (b < 0.0f) {
-          if (top[1]) { b = dmin32; a = 0.0f; } else { b = 0.0f; }
-        }
-        // loop 2: above y_max
-        if (a > ymax32) {
-          if (top[0]) { a = ymax32; } else { a = ymd32; b = ymax32; }
-        }
-        if (b > ymax32) {
-          if (top[1]) { b = ymax32; } else { b = ymd32; a = ymax32; }
-        }
-        // loop 3: pair closer than d_min -> lift the top node
-        if (top[0] && fabsf(a - b) < dmin32) a = b + dmin32;
-        if (top[1] && fabsf(b - a) < dmin32) b = a + dmin32;
-        Y[nd[0]] = a;
-        Y[nd[1]] = b;
+    float *Y = ysh(T), *GE = geosh(T), *TA = tac(T);
+    const int16_t *PR = t_pairs(T);
+    const uint8_t *NF = t_nflags(T);
+    for (int p = g; p < T.NP; p += G) {
+      const int n0 = PR[2 * p], n1 = PR[2 * p + 1];
+      const float y0 = Y[n0], y1 = Y[n1];
+      const int f0 = NF[n0], f1 = NF[n1];
+      const bool top0 = f0 & TF_TOP, top1 = f1 & TF_TOP;
+      float ga0 = tb_clamp01(GE[2 * n0]), ga1 = tb_clamp01(GE[2 * n0 + 1]);
+      float gb0 = tb_clamp01(GE[2 * n1]), gb1 = tb_clamp01(GE[2 * n1 + 1]);
+      float ta[3], tb[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        ta[j] = tb_clamp01(TA[3 * n0 + j]);
+        tb[j] = tb_clamp01(TA[3 * n1 + j]);
+        TA[3 * n0 + j] = ta[j];
+        TA[3 * n1 + j] = tb[j];
       }
-    } else {
-      for (int n = g; n < T.N; n += G) {
-        Y[n] = A.y_in[bn + n];
-        X[n] = A.x[bn + n];
+      if ((A.flags & TB_CLAMP_INPLACE) && active) {  // truss2D_ENV.py:376-388 mutates the caller's arrays
+        A.a_geo[(bn + n0) * 2 + 0] = ga0;
+        A.a_geo[(bn + n0) * 2 + 1] = ga1;
+        A.a_geo[(bn + n1) * 2 + 0] = gb0;
+        A.a_geo[(bn + n1) * 2 + 1] = gb1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          A.a_topo[(bn + n0) * 3 + j] = ta[j];
+          A.a_topo[(bn + n1) * 3 + j] = tb[j];
+        }
       }
+      float mu0, md0, mu1, md1;
+      if (A.mu_in) {
+        mu0 = A.mu_in[bn + n0];
+        md0 = A.md_in[bn + n0];
+        mu1 = A.mu_in[bn + n1];
+        md1 = A.md_in[bn + n1];
+      } else {
+        move_range(top0, y0, y1, mu0, md0);
+        move_range(top1, y1, y0, mu1, md1);
+      }
+      float a = move_node(y0, ga0, ga1, mu0, md0, f0 & TF_RESY);
+      float b = move_node(y1, gb0, gb1, mu1, md1, f1 & TF_RESY);
+      // sequential repairs (truss2D_ENV.py:469-490): visit lo then hi in each of the three loops
+      // loop 1: below y_min (= 0)
+      if (a < 0.0f) {
+        if (top0) { a = dmin32; b = 0.0f; } else { a = 0.0f; }
+      }
+      if (b < 0.0f) {
+        if (top1) { b = dmin32; a = 0.0f; } else { b = 0.0f; }
+      }
+      // loop 2: above y_max
+      if (a > ymax32) {
+        if (top0) { a = ymax32; } else { a = ymd32; b = ymax32; }
+      }
+      if (b > ymax32) {
+        if (top1) { b = ymax32; } else { b = ymd32; a = ymax32; }
+      }
+      // loop 3: pair closer than d_min -> lift the top node
+      if (top0 && fabsf(a - b) < dmin32) a = b + dmin32;
+      if (top1 && fabsf(b - a) < dmin32) b = a + dmin32;
+      Y[n0] = a;
+      Y[n1] = b;
     }
-    // clear the band (identity on padding rows), the reaction buffer and the zero slot
-    double *K = kb(T);
-    const int tot = (T.n_pad + W) * W;
-    for (int i = g; i < tot; i += G) K[i] = ((i % W) == 0 && (i / W) >= T.ndof) ? 1.0 : 0.0;
-    double *RB = rbuf(T);
-    for (int i = g; i < T.n_rest; i += G) RB[i] = 0.0;
-    if (g == 0) xsol(T)[T.n_pad] = 0.0;
   }
 
   // ---- phase 2 (only when the topology has mirror tables): node symmetry ----
   TRUSS_HD void phase_sym_nodes(const TopoDev &T) {
     float *Y = ysh(T);
+    const int16_t *SN = t_symn(T);
     for (int i = g; i < T.n_sym_nodes; i += G) {
-      int dst = T.sym_nodes[2 * i], src = T.sym_nodes[2 * i + 1];
+      int dst = SN[2 * i], src = SN[2 * i + 1];
       float v = heads ? Y[src] : Y[dst];
       Y[dst] = v;
       Y[src] = v;
     }
   }
 
-  // ---- phase 3: section update (truss2D_ENV.py:421-466) ----
+  // ---- phase 3: section update (truss2D_ENV.py:421-466), in place in LDS ----
   TRUSS_HD void phase_sizing(const TopoDev &T, const StepArgsDev &A) {
-    const size_t be = (size_t)envc * T.E;
+    if (A.flags & TB_NO_DECODE) return;
     const float *TA = tac(T);
-    const bool decode = !(A.flags & TB_NO_DECODE);
+    int32_t *S = secsh(T);
+    const int16_t *CN = t_conn(T);
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
-      int e = g + G * i;
-      int s = 0;
-      if (e < T.E) {
-        s = A.sec_in[be + e];
-        if (decode) {
-          int n0 = T.conn[2 * e], n1 = T.conn[2 * e + 1];
-          float p0 = TA[n0 * 3 + 0] + TA[n1 * 3 + 0];
-          float p1 = TA[n0 * 3 + 1] + TA[n1 * 3 + 1];
-          float p2 = TA[n0 * 3 + 2] + TA[n1 * 3 + 2];
-          int am = 0;
-          float best = p0;
-          if (p1 > best) { am = 1; best = p1; }
-          if (p2 > best) { am = 2; }
-          if (am == 0) s = s > 0 ? s - 1 : 0;
-          else if (am == 1) s = s < T.n_sections - 1 ? s + 1 : T.n_sections - 1;
-        }
-        if (T.n_sym_elems > 0) secsh(T)[e] = s;
-      }
-      esec[i] = s;
+      const int e = g + G * i;
+      const int ee = e < T.E ? e : T.E - 1;
+      const int n0 = CN[2 * ee], n1 = CN[2 * ee + 1];
+      int s = S[ee];
+      float p0 = TA[n0 * 3 + 0] + TA[n1 * 3 + 0];
+      float p1 = TA[n0 * 3 + 1] + TA[n1 * 3 + 1];
+      float p2 = TA[n0 * 3 + 2] + TA[n1 * 3 + 2];
+      int am = 0;
+      float best = p0;
+      if (p1 > best) { am = 1; best = p1; }
+      if (p2 > best) { am = 2; }
+      int sdn = s > 0 ? s - 1 : 0, sup = s < T.n_sections - 1 ? s + 1 : T.n_sections - 1;
+      s = am == 0 ? sdn : (am == 1 ? sup : s);
+      if (e < T.E) S[e] = s;
     }
   }
 
   TRUSS_HD void phase_sym_elems(const TopoDev &T) {
     int32_t *S = secsh(T);
+    const int16_t *SE = t_syme(T);
     for (int i = g; i < T.n_sym_elems; i += G) {
-      int a = T.sym_elems[2 * i], b = T.sym_elems[2 * i + 1];
+      int a = SE[2 * i], b = SE[2 * i + 1];
       int m = S[a] < S[b] ? S[a] : S[b];
       S[a] = m;
       S[b] = m;
     }
   }
 
-  TRUSS_HD void phase_sym_reload(const TopoDev &T) {
-    const int32_t *S = secsh(T);
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-      int e = g + G * i;
-      if (e < T.E) esec[i] = S[e];
-    }
-  }
-
   TRUSS_HD double load_at(const TopoDev &T, int r) const {
     if (r >= T.n_pad) return 0.0;
-    int nd = T.posnode[r];
+    int nd = t_posnode(T)[r];
     if (nd < 0) return 0.0;
-    int fl = T.nflags[nd >> 1] & (is_roof ? TF_LOAD_ROOF : TF_LOAD_BRIDGE);
+    int fl = t_nflags(T)[nd >> 1] & (is_roof ? TF_LOAD_ROOF : TF_LOAD_BRIDGE);
     if (!fl) return 0.0;
     return (nd & 1) ? load_y : load_x;
   }
@@ -323,42 +444,94 @@ struct StepLane {
   // ---- phase 4: element stiffness + scatter-add into the LDS band; load vector ----
   TRUSS_HD void phase_elements(const TopoDev &T, const StepArgsDev &A) {
     const float *Y = ysh(T), *X = xsh(T);
+    const int32_t *S = secsh(T);
+    const int16_t *CN = t_conn(T);
+    const double *AR = t_area(T), *ISR = t_isr(T);
     double *K = kb(T);
-    const size_t be = (size_t)envc * T.E;
+    double kcc[EPL], kcs[EPL], kss[EPL];
+    // pass 1: gather + arithmetic for all of the lane's elements (no control flow: the square roots
+    // and divisions of different elements overlap)
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
-      int e = g + G * i;
-      ek[i] = ec[i] = es[i] = 0.0;
-      eA[i] = 1.0;
+      const int e = g + G * i;
+      const int ee = e < T.E ? e : T.E - 1;
+      const int n0 = CN[2 * ee], n1 = CN[2 * ee + 1];
+      const int sc = S[ee];
+      const double dx = (double)X[n1] - (double)X[n0];
+      const double dy = (double)Y[n1] - (double)Y[n0];
+      const double l2 = dx * dx + dy * dy;
+      const double rl = tb_rsqrt(l2);  // 1/L: v_rsq_f64 seed + Newton (no f64 sqrt/div sequences)
+      const double len = l2 * rl;
+      const double c = dx * rl, s = dy * rl;
+      const double Aa = AR[sc];
+      const double k = (T.e_mod * Aa) * rl;
+      ek[i] = k;
+      ec[i] = c;
+      es[i] = s;
+      ei[i] = ISR[sc];
+      if (e < T.E) p_vol += (double)(float)(Aa * len);  // all_v[i] is a float32 store (ENV:508)
+      const double kc = k * c, ks = k * s;
+      kcc[i] = kc * c;
+      kcs[i] = kc * s;
+      kss[i] = ks * s;
+    }
+    // pass 2 (FEM_2Dtruss.py:320-324 restricted to the lower band, without atomics): the four
+    // off-diagonal entries of an element belong to that element alone -> plain stores; the element's
+    // (k cc, k cs, k ss) go to LDS for the node-diagonal gather of phase_assemble_nodes.
+    const int32_t *AC = t_asm(T);
+    double *EV = evsh(T);
+    if (g == 0) EV[3 * T.E] = EV[3 * T.E + 1] = EV[3 * T.E + 2] = 0.0;  // slot the padded adjacency points at
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const int e = g + G * i;
       if (e < T.E) {
-        int n0 = T.conn[2 * e], n1 = T.conn[2 * e + 1];
-        double dx = (double)X[n1] - (double)X[n0];
-        double dy = (double)Y[n1] - (double)Y[n0];
-        double len = sqrt(dx * dx + dy * dy);
-        double c = dx / len, s = dy / len;
-        double Aa = T.sec_area[esec[i]];
-        double k = T.e_mod * Aa / len;
-        ek[i] = k;
-        ec[i] = c;
-        es[i] = s;
-        eA[i] = Aa;
-        p_vol += (double)(float)(Aa * len);  // all_v[i] is a float32 store (ENV:508)
-        double kc = k * c, ks = k * s;
-        const double kcc = kc * c, kcs = kc * s, kss = ks * s;
-        const int32_t *code = T.asm_code + e * 10;
-        for (int t = 0; t < 10; ++t) {
-          int cd = code[t];
-          if (cd >= 0) {
-            int ty = (cd >> 1) & 3;
-            double v = ty == 0 ? kcc : (ty == 1 ? kcs : kss);
-            tb_lds_add(&K[cd >> 3], (cd & 1) ? -v : v);
-          }
-        }
-        if (A.sec_out && active) A.sec_out[be + e] = esec[i];
+        EV[3 * e + 0] = kcc[i];
+        EV[3 * e + 1] = kcs[i];
+        EV[3 * e + 2] = kss[i];
+        const int32_t *code = AC + e * 10 + 6;
+        const int c0 = code[0], c1 = code[1], c2 = code[2], c3 = code[3];
+        if (c0 >= 0) K[c0 >> 3] = -kcc[i];
+        if (c1 >= 0) K[c1 >> 3] = -kss[i];
+        if (c2 >= 0) K[c2 >> 3] = -kcs[i];
+        if (c3 >= 0) K[c3 >> 3] = -kcs[i];
       }
     }
+  }
+
+  // ---- phase 5: node-diagonal 2x2 blocks = sum over incident elements in ascending element order
+  // (deterministic).  The adjacency is padded to NDEG entries per node so the gather is straight-line
+  // code and its LDS reads overlap.
+  TRUSS_HD void phase_assemble_nodes(const TopoDev &T) {
+    const double *EV = evsh(T);
+    const int16_t *AD = t_adj8(T), *DP = t_dofpos(T);
+    double *K = kb(T);
+    for (int n = g; n < T.N; n += G) {
+      double cc = 0.0, cs = 0.0, ss = 0.0;
+#pragma unroll
+      for (int a = 0; a < NDEG; ++a) {
+        const int e = AD[n * NDEG + a];
+        cc += EV[3 * e + 0];
+        cs += EV[3 * e + 1];
+        ss += EV[3 * e + 2];
+      }
+      const int px = DP[2 * n], py = DP[2 * n + 1];
+      if (px >= 0) K[px * W] = cc;
+      if (py >= 0) K[py * W] = ss;
+      if (px >= 0 && py >= 0) {
+        const int hi = px > py ? px : py, lo = px > py ? py : px;
+        K[hi * W + (hi - lo)] = cs;
+      }
+    }
+    for (int r = T.ndof + g; r < T.n_pad + W; r += G) K[r * W] = 1.0;  // padding rows: identity
+  }
+
+  // ---- phase 5b: the element-value buffer is dead; its bytes become the solver scratch ----
+  TRUSS_HD void solver_scratch_init(const TopoDev &T) {
     double *Z = zs(T);
-    for (int r = g; r < T.n_pad + W; r += G) Z[r] = load_at(T, r);
+    for (int r = g; r < T.n_pad + W; r += G) Z[r] = load_at(T, r);  // load vector P by solver position
+    double *RB = rbuf(T);
+    for (int i = g; i < T.n_rest; i += G) RB[i] = 0.0;
+    if (g == 0) xsol(T)[T.n_pad] = 0.0;
   }
 
   // ---- solver -------------------------------------------------------------------------------
@@ -367,7 +540,7 @@ struct StepLane {
     const double *Z = zs(T);
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
-      int r = g + G * s;
+      int r = gs + WL * s;
 #pragma unroll
       for (int c = 0; c < W; ++c) R[s][c] = (c <= r) ? K[r * W + (r - c)] : K[c * W + (c - r)];
       rhs[s] = Z[r];
@@ -376,12 +549,16 @@ struct StepLane {
     for (int j = 0; j < W; ++j) xs[j] = 0.0;
   }
 
-  // post this lane's entries of pivot column k (kk = k mod W, compile-time after unrolling)
+  // post this lane's entries of pivot column k (kk = k mod W, compile-time after unrolling) and its
+  // right-hand sides; no predication: mirror lanes store the same values to the same addresses
   TRUSS_HD void pivot_write(const TopoDev &T, int k, int kk) {
     double *K = kb(T);
+    double *ZR = zring(T) + (k & 1) * W;
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) K[k * W + g + G * s] = R[s][kk];
-    if (g == kk % G) zs(T)[k] = rhs[kk / G];
+    for (int s = 0; s < RPL; ++s) {
+      K[k * W + gs + WL * s] = R[s][kk];
+      ZR[gs + WL * s] = rhs[s];
+    }
   }
 
   TRUSS_HD void pivot_update(const TopoDev &T, int k, int kk) {
@@ -389,11 +566,12 @@ struct StepLane {
     double col[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) col[j] = K[k * W + j];
-    const double zk = zs(T)[k];
+    const double zk = zring(T)[(k & 1) * W + kk];
     const double d = col[kk];
     if (!(d > 0.0)) bad = 1;
     const double inv = tb_rcp(d);
-    if (g == kk % G) dinv(T)[k] = inv;
+    dinv(T)[k] = inv;  // every lane stores the same value
+    zs(T)[k] = zk;     // z_k replaces P_k (P_k was consumed when row k entered the window)
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
       double l = R[s][kk] * inv;
@@ -407,11 +585,11 @@ struct StepLane {
     const double *Kn = K + rn * W;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
-      int o = (g + G * s - kk + W) % W;  // this row is k+o; it needs K[k+W][k+o] = band entry W-o
+      int o = (gs + WL * s - kk + W) % W;  // this row is k+o; it needs K[k+W][k+o] = band entry W-o
       R[s][kk] = Kn[(W - o) % W];
     }
-    if (g == kk % G) {
-      const int sp = kk / G;
+    if (gs == kk % WL) {
+      const int sp = kk / WL;
 #pragma unroll
       for (int j = 1; j < W; ++j) R[sp][(kk + j) % W] = Kn[W - j];
       rhs[sp] = zs(T)[rn];
@@ -427,39 +605,50 @@ struct StepLane {
       if (j != kk) acc = fma(-K[k * W + j], xs[j], acc);
     double xk = acc * dinv(T)[k];
     xs[kk] = xk;
-    if (g == 0) xsol(T)[k] = xk;
+    xsol(T)[k] = xk;
   }
+
+  // Output staging: after the back substitution the band region is dead; the per-env result rows are
+  // built there and streamed to HBM as whole rows with 16-byte stores (phase_store).
+  //   [q0 E f32][sr E f32][disp 2N f32][mu N f32][md N f32][comp E u8]
+  TRUSS_HD float *oq0(const TopoDev &T) { return (float *)(L + T.o_kb + T.so_q0); }
+  TRUSS_HD float *osr(const TopoDev &T) { return (float *)(L + T.o_kb + T.so_sr); }
+  TRUSS_HD float *odisp(const TopoDev &T) { return (float *)(L + T.o_kb + T.so_disp); }
+  TRUSS_HD float *omu(const TopoDev &T) { return (float *)(L + T.o_kb + T.so_mu); }
+  TRUSS_HD float *omd(const TopoDev &T) { return (float *)(L + T.o_kb + T.so_md); }
+  TRUSS_HD uint8_t *ocomp(const TopoDev &T) { return (uint8_t *)(L + T.o_kb + T.so_comp); }
 
   // ---- phase 6: member forces, stress ratios, reactions (FEM_2Dtruss.py:341-431) ----
   TRUSS_HD void phase_post_elements(const TopoDev &T, const StepArgsDev &A) {
     const double *XS = xsol(T);
+    const int16_t *CN = t_conn(T), *DP = t_dofpos(T), *RS = t_restslot(T);
     const size_t be = (size_t)envc * T.E;
     const int zslot = T.n_pad;
+    float *Q = oq0(T), *SR = osr(T);
+    uint8_t *CP = ocomp(T);
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
-      int e = g + G * i;
+      const int e = g + G * i;
+      const int ee = e < T.E ? e : T.E - 1;
+      const int n0 = CN[2 * ee], n1 = CN[2 * ee + 1];
+      const int p0 = DP[2 * n0], p1 = DP[2 * n0 + 1], p2 = DP[2 * n1], p3 = DP[2 * n1 + 1];
+      const double v0 = XS[p0 < 0 ? zslot : p0], v1 = XS[p1 < 0 ? zslot : p1];
+      const double v2 = XS[p2 < 0 ? zslot : p2], v3 = XS[p3 < 0 ? zslot : p3];
+      const double c = ec[i], s = es[i], k = ek[i];
+      const double u0 = c * v0 + s * v1;
+      const double u2 = c * v2 + s * v3;
+      const double q = k * u0 + (-k) * u2;
+      const float srf = (float)(fabs(q) * ei[i]);  // |q/A| / long_stress (FEM:419,429)
       if (e < T.E) {
-        int n0 = T.conn[2 * e], n1 = T.conn[2 * e + 1];
-        int p0 = T.dofpos[2 * n0], p1 = T.dofpos[2 * n0 + 1], p2 = T.dofpos[2 * n1], p3 = T.dofpos[2 * n1 + 1];
-        double v0 = XS[p0 < 0 ? zslot : p0], v1 = XS[p1 < 0 ? zslot : p1];
-        double v2 = XS[p2 < 0 ? zslot : p2], v3 = XS[p3 < 0 ? zslot : p3];
-        double c = ec[i], s = es[i], k = ek[i];
-        double u0 = c * v0 + s * v1;
-        double u2 = c * v2 + s * v3;
-        double q = k * u0 + (-k) * u2;
-        double srr = fabs(q / eA[i]) / T.long_stress;
-        float srf = (float)srr;
         p_c1 = fmaxf(p_c1, fabsf(srf));
-        if (active) {
-          A.q0[be + e] = (float)q;
-          A.sr[be + e] = srf;
-          A.comp[be + e] = q > 0.0 ? 1 : 0;
-          if (A.q064) A.q064[be + e] = q;
-        }
+        Q[e] = (float)q;
+        SR[e] = srf;
+        CP[e] = q > 0.0 ? 1 : 0;
+        if (A.q064 && active) A.q064[be + e] = q;
         if (A.react) {
           // f = T^T q = q0 * [c, s, -c, -s] summed into the restrained DOFs (FEM:389-411)
-          int s0 = T.restslot[2 * n0], s1 = T.restslot[2 * n0 + 1];
-          int s2 = T.restslot[2 * n1], s3 = T.restslot[2 * n1 + 1];
+          int s0 = RS[2 * n0], s1 = RS[2 * n0 + 1];
+          int s2 = RS[2 * n1], s3 = RS[2 * n1 + 1];
           if (s0 >= 0) tb_lds_add(&rbuf(T)[s0], q * c);
           if (s1 >= 0) tb_lds_add(&rbuf(T)[s1], q * s);
           if (s2 >= 0) tb_lds_add(&rbuf(T)[s2], q * (-c));
@@ -469,45 +658,37 @@ struct StepLane {
     }
   }
 
-  // ---- phase 7: nodal outputs, move ranges of the new design, objective partials ----
+  // ---- phase 7: nodal results, move ranges of the new design, objective partials ----
   TRUSS_HD void phase_post_nodes(const TopoDev &T, const StepArgsDev &A) {
     const double *XS = xsol(T);
-    const float *Y = ysh(T);
+    const float *Y = ysh(T), *TG = tgsh(T);
+    const int16_t *DP = t_dofpos(T), *PR = t_pairs(T);
+    const uint8_t *NF = t_nflags(T);
     const size_t bn = (size_t)envc * T.N;
     const int zslot = T.n_pad;
+    float *DS = odisp(T), *MU = omu(T), *MD = omd(T);
     for (int n = g; n < T.N; n += G) {
-      int px = T.dofpos[2 * n], py = T.dofpos[2 * n + 1];
+      int px = DP[2 * n], py = DP[2 * n + 1];
       double dx = XS[px < 0 ? zslot : px], dy = XS[py < 0 ? zslot : py];
-      bool top = T.nflags[n] & TF_TOP;
+      bool top = NF[n] & TF_TOP;
       float y = Y[n];
       if (top) {
-        float tg = A.target[bn + n];
-        p_dt += (double)fabsf(tg - y);  // all_dt (ENV:514)
+        p_dt += (double)fabsf(TG[n] - y);  // all_dt (ENV:514)
       } else {
         p_c2 = fmaxf(p_c2, fabsf((float)(dy / max_def)));  // all_d (ENV:516)
       }
-      if (active) {
-        A.y_out[bn + n] = y;
-        A.disp[(bn + n) * 2 + 0] = (float)dx;
-        A.disp[(bn + n) * 2 + 1] = (float)dy;
-        if (A.disp64) {
-          A.disp64[(bn + n) * 2 + 0] = dx;
-          A.disp64[(bn + n) * 2 + 1] = dy;
-        }
+      DS[2 * n + 0] = (float)dx;
+      DS[2 * n + 1] = (float)dy;
+      if (A.disp64 && active) {
+        A.disp64[(bn + n) * 2 + 0] = dx;
+        A.disp64[(bn + n) * 2 + 1] = dy;
       }
     }
     if (A.mu_out && T.has_pairs) {
       for (int p = g; p < T.NP; p += G) {
-        int lo = T.pairs[2 * p], hi = T.pairs[2 * p + 1];
-        float ul, dl, uh, dh;
-        move_range(T.nflags[lo] & TF_TOP, Y[lo], Y[hi], ul, dl);
-        move_range(T.nflags[hi] & TF_TOP, Y[hi], Y[lo], uh, dh);
-        if (active) {
-          A.mu_out[bn + lo] = ul;
-          A.md_out[bn + lo] = dl;
-          A.mu_out[bn + hi] = uh;
-          A.md_out[bn + hi] = dh;
-        }
+        int lo = PR[2 * p], hi = PR[2 * p + 1];
+        move_range(NF[lo] & TF_TOP, Y[lo], Y[hi], MU[lo], MD[lo]);
+        move_range(NF[hi] & TF_TOP, Y[hi], Y[lo], MU[hi], MD[hi]);
       }
     }
     if (A.energy)
@@ -518,6 +699,39 @@ struct StepLane {
     RD[2 * G + g] = (double)p_c1;
     RD[3 * G + g] = (double)p_c2;
     RD[4 * G + g] = p_en;
+  }
+
+  // copy one result row LDS -> HBM with the env's own G lanes (16-byte stores when possible)
+  TRUSS_HD void store_row(void *dst, const void *src, int nbytes) const {
+    if ((nbytes & 15) == 0 && (((size_t)dst) & 15) == 0) {
+      const tb_u4 *s4 = (const tb_u4 *)src;
+      tb_u4 *d4 = (tb_u4 *)dst;
+      for (int q = g; q < (nbytes >> 4); q += G) d4[q] = s4[q];
+    } else if ((nbytes & 3) == 0) {
+      const uint32_t *s1 = (const uint32_t *)src;
+      uint32_t *d1 = (uint32_t *)dst;
+      for (int q = g; q < (nbytes >> 2); q += G) d1[q] = s1[q];
+    } else {
+      const uint8_t *s1 = (const uint8_t *)src;
+      uint8_t *d1 = (uint8_t *)dst;
+      for (int q = g; q < nbytes; q += G) d1[q] = s1[q];
+    }
+  }
+
+  // ---- phase 8a: stream the result rows out ----
+  TRUSS_HD void phase_store(const TopoDev &T, const StepArgsDev &A) {
+    if (!active) return;
+    const size_t bn = (size_t)env * T.N, be = (size_t)env * T.E;
+    store_row(A.y_out + bn, ysh(T), 4 * T.N);
+    if (A.sec_out) store_row(A.sec_out + be, secsh(T), 4 * T.E);
+    store_row(A.q0 + be, oq0(T), 4 * T.E);
+    store_row(A.sr + be, osr(T), 4 * T.E);
+    store_row(A.comp + be, ocomp(T), T.E);
+    store_row(A.disp + bn * 2, odisp(T), 8 * T.N);
+    if (A.mu_out && T.has_pairs) {
+      store_row(A.mu_out + bn, omu(T), 4 * T.N);
+      store_row(A.md_out + bn, omd(T), 4 * T.N);
+    }
   }
 
   // ---- phase 8: one lane per env folds the partials (fixed order) and writes point ----
@@ -559,15 +773,23 @@ struct StepLane {
 //   BAR()       explicit barrier
 // W_ must be a constexpr in scope; TRUSS_UNROLL expands to the unroll pragma on the GPU so that the
 // register-window indices (kk_) are compile-time constants.
+#ifndef TRUSS_ST
+#define TRUSS_ST(i)  // phase time stamp hook (diagnostic build only)
+#endif
 #define TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)                                   \
+  TRUSS_ST(0);                                                                      \
+  PH(phase_stage(T, A));                                                            \
+  TRUSS_ST(1);                                                                      \
   PH(phase_decode(T, A));                                                           \
   if ((T).n_sym_nodes > 0 && !((A).flags & TB_NO_DECODE)) { PH(phase_sym_nodes(T)); } \
+  TRUSS_ST(2);                                                                      \
   PH(phase_sizing(T, A));                                                           \
-  if ((T).n_sym_elems > 0) {                                                        \
-    if (!((A).flags & TB_NO_DECODE)) { PH(phase_sym_elems(T)); }                    \
-    PH(phase_sym_reload(T));                                                        \
-  }                                                                                 \
+  if ((T).n_sym_elems > 0 && !((A).flags & TB_NO_DECODE)) { PH(phase_sym_elems(T)); } \
+  TRUSS_ST(3);                                                                      \
   PH(phase_elements(T, A));                                                         \
+  PH(phase_assemble_nodes(T));                                                      \
+  PH(solver_scratch_init(T));                                                       \
+  TRUSS_ST(4);                                                                      \
   PH(solver_init(T));                                                               \
   for (int kb_ = 0; kb_ < (T).n_pad; kb_ += W_) {                                   \
     TRUSS_UNROLL                                                                    \
@@ -577,14 +799,20 @@ struct StepLane {
     }                                                                               \
   }                                                                                 \
   BAR();                                                                            \
+  TRUSS_ST(5);                                                                      \
   for (int kb_ = (T).n_pad - W_; kb_ >= 0; kb_ -= W_) {                             \
     TRUSS_UNROLL                                                                    \
     for (int kk_ = W_ - 1; kk_ >= 0; --kk_) { PH_NS(backsub_step(T, kb_ + kk_, kk_)); } \
   }                                                                                 \
   BAR();                                                                            \
+  TRUSS_ST(6);                                                                      \
   PH(phase_post_elements(T, A));                                                    \
+  TRUSS_ST(7);                                                                      \
   PH(phase_post_nodes(T, A));                                                       \
-  PH_NS(phase_finish(T, A));
+  TRUSS_ST(8);                                                                      \
+  PH_NS(phase_store(T, A));                                                         \
+  PH_NS(phase_finish(T, A));                                                        \
+  TRUSS_ST(9);
 
 // ================================================================================================
 // Observation tensors: state_data + state_data_not_norm (truss2D_ENV.py:40-193).
@@ -627,7 +855,7 @@ struct ObsLane {
     const size_t bn = (size_t)env * T.N;
     float *R = raw();
     for (int n = lane; n < T.N; n += 64) {
-      const int fl = T.nflags[n];
+      const int fl = TB_TAB(uint8_t, T.blob, T.f_nflags)[n];
       const float top = (fl & TF_TOP) ? 1.0f : 0.0f;
       const float y = A.y[bn + n];
       float f[13];
@@ -673,11 +901,13 @@ struct ObsLane {
     }
     const size_t be = (size_t)env * T.E;
     float *As = mats(T), *Ats = As + T.N * T.N, *Acs = Ats + T.N * T.N;
-    const double amax = T.sec_area[T.n_sections - 1];
+    const double *AR = TB_TAB(double, T.blob, T.f_area);
+    const int16_t *CN = TB_TAB(int16_t, T.blob, T.f_conn);
+    const double amax = AR[T.n_sections - 1];
     for (int e = lane; e < T.E; e += 64) {
-      const int a = T.conn[2 * e], b = T.conn[2 * e + 1];
+      const int a = CN[2 * e], b = CN[2 * e + 1];
       const int s = A.sec[be + e];
-      const double area = T.sec_area[s];
+      const double area = AR[s];
       const float srv = A.sr[be + e];
       const int cmp = A.comp[be + e];
       const float vs = (float)(area / amax);

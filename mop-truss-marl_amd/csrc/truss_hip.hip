@@ -26,14 +26,34 @@ __device__ __forceinline__ double tb_rcp(double d) {
   return r;
 }
 
+#ifdef TRUSS_STAMPS
+// Diagnostic build only (make diag): lane 0 of one mid-grid workgroup records s_memtime at the phase
+// boundaries into a buffer nothing else reads.  Never enabled in libtruss_mi355.so.
+__device__ unsigned long long g_truss_stamps[16];
+#define TRUSS_ST(i)                                                  \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_truss_stamps[i] = clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+#endif
+
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps
+__device__ __forceinline__ double tb_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  return r;
+}
+
 #include "truss_body.h"
 
-template <int G, int RPL, int EPL>
+template <int G, int WL, int RPL, int EPL>
 __global__ __launch_bounds__(64) void truss_step_kernel(const TopoDev T, const StepArgsDev A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  StepLane<G, RPL, EPL> ln;
+  StepLane<G, WL, RPL, EPL> ln;
   ln.init(threadIdx.x, blockIdx.x, T, A, smem);
-  constexpr int W_ = StepLane<G, RPL, EPL>::W;
+  constexpr int W_ = StepLane<G, WL, RPL, EPL>::W;
 #define PH(call) \
   ln.call;       \
   __syncthreads()
@@ -87,11 +107,11 @@ static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream)
   return TRUSS_OK;
 }
 
-template <int G, int RPL, int EPL>
+template <int G, int WL, int RPL, int EPL>
 static int hip_run(const truss_topo *t, const StepArgsDev &A, hipStream_t st) {
   static bool attr_set = false;
   static size_t attr_bytes = 0;
-  auto kern = truss_step_kernel<G, RPL, EPL>;
+  auto kern = truss_step_kernel<G, WL, RPL, EPL>;
   if (!attr_set || t->lds_bytes > attr_bytes) {  // dynamic LDS beyond 64 KiB needs the opt-in
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return tb_fail(TRUSS_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -109,10 +129,15 @@ static int hip_run(const truss_topo *t, const StepArgsDev &A, hipStream_t st) {
 static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *stream) {
   const TbVariant &v = kVariants[t->variant];
   hipStream_t st = (hipStream_t)stream;
-#define CASE(g, r, e) \
-  if (v.G == g && v.RPL == r && v.EPL == e) return hip_run<g, r, e>(t, A, st);
-  CASE(8, 1, 5) CASE(8, 1, 10) CASE(8, 2, 5) CASE(8, 2, 10) CASE(16, 1, 3) CASE(16, 1, 5)
-  CASE(4, 2, 10) CASE(4, 2, 20) CASE(4, 4, 20)
-#undef CASE
+#define X(g, wl, r, e) \
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) return hip_run<g, wl, r, e>(t, A, st);
+  TRUSS_VARIANTS(X)
+#undef X
   return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled");
 }
+
+#ifdef TRUSS_STAMPS
+extern "C" int truss_debug_stamps(unsigned long long *out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_truss_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -27,10 +27,14 @@ static int tb_fail(int code, const std::string &msg) {
 
 // compiled (G, RPL, EPL) instantiations of the step kernel; keep in sync with the dispatch tables
 struct TbVariant {
-  int G, RPL, EPL;
+  int G, WL, RPL, EPL;  // lanes per env, window lanes, rows per lane, elements per lane
 };
+#define TRUSS_VARIANTS(X) \
+  X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(8, 8, 2, 10) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20)
 static const TbVariant kVariants[] = {
-    {8, 1, 5}, {8, 1, 10}, {8, 2, 5}, {8, 2, 10}, {16, 1, 3}, {16, 1, 5}, {4, 2, 10}, {4, 2, 20}, {4, 4, 20},
+#define X(g, wl, r, e) {g, wl, r, e},
+    TRUSS_VARIANTS(X)
+#undef X
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -40,7 +44,7 @@ static inline size_t tb_obs_lds_bytes(int N) {
 
 struct truss_topo {
   int N = 0, E = 0, NP = 0, ndof = 0, n_pad = 0, n_rest = 0, bw = 0;
-  int G = 0, RPL = 0, EPL = 0, W = 0, variant = -1;
+  int G = 0, WL = 0, RPL = 0, EPL = 0, W = 0, variant = -1;
   std::vector<int32_t> nsc, ttnsc, perm;
   TopoDev dev{};
   void *blob = nullptr;
@@ -149,6 +153,11 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   for (int i = 0; i < n_sym_elems * 2; ++i)
     if (sym_elems[i] < 0 || sym_elems[i] >= E) return tb_fail(TRUSS_EINVAL, "sym_elems out of range");
 
+  for (int e = 0; e < E; ++e)
+    for (int f = e + 1; f < E; ++f)
+      if ((conn[2 * e] == conn[2 * f] && conn[2 * e + 1] == conn[2 * f + 1]) ||
+          (conn[2 * e] == conn[2 * f + 1] && conn[2 * e + 1] == conn[2 * f]))
+        return tb_fail(TRUSS_EUNSUPPORTED, "two elements join the same pair of nodes (parallel members are not supported)");
   truss_topo *t = new truss_topo();
   t->N = N;
   t->E = E;
@@ -223,20 +232,22 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   t->bw = tb_bandwidth(cands[best], res, conn, N, E, &dofpos);
 
   // ---- kernel variant: smallest window that holds the band; TRUSS_LANES / TRUSS_RPL override ----
-  int want_G = tb_env_int("TRUSS_LANES", 0), want_RPL = tb_env_int("TRUSS_RPL", 0);
+  // Preference (TRUSS_LANES / TRUSS_WLANES / TRUSS_RPL override): the narrowest window that holds the
+  // band; 16 lanes per env (4 envs per wave) so that a 4096-env batch puts a wave on every SIMD.
+  int want_G = tb_env_int("TRUSS_LANES", 0), want_WL = tb_env_int("TRUSS_WLANES", 0), want_RPL = tb_env_int("TRUSS_RPL", 0);
   int pick = -1;
   auto score = [&](const TbVariant &v) {
-    // default preference: 8 lanes for narrow bands, 16 lanes for wide ones, then smaller windows
-    int W = v.G * v.RPL;
-    int pref = (W == 8 && v.G == 8) ? 0 : (W == 16 && v.G == 16) ? 1 : (v.G == 8) ? 2 : 3;
-    return W * 1000 + pref * 100 + v.EPL;
+    int W = v.WL * v.RPL;
+    int pref = (v.G == 16 && v.WL == 8) ? 0 : (v.G == 8 && v.WL == 8) ? 1 : (v.G == 16) ? 2 : 3;
+    return W * 10000 + v.RPL * 1000 + pref * 100 + v.EPL;
   };
   for (int i = 0; i < kNumVariants; ++i) {
     const TbVariant &v = kVariants[i];
-    int W = v.G * v.RPL;
+    int W = v.WL * v.RPL;
     if (W <= t->bw) continue;
     if ((E + v.G - 1) / v.G > v.EPL) continue;
     if (want_G && v.G != want_G) continue;
+    if (want_WL && v.WL != want_WL) continue;
     if (want_RPL && v.RPL != want_RPL) continue;
     if (pick < 0 || score(v) < score(kVariants[pick])) pick = i;
   }
@@ -249,9 +260,10 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   }
   t->variant = pick;
   t->G = kVariants[pick].G;
+  t->WL = kVariants[pick].WL;
   t->RPL = kVariants[pick].RPL;
   t->EPL = kVariants[pick].EPL;
-  t->W = t->G * t->RPL;
+  t->W = t->WL * t->RPL;
   const int W = t->W;
   t->n_pad = ((t->ndof + W - 1) / W) * W;
 
@@ -324,18 +336,34 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   std::vector<double> area(n_sections);
   for (int i = 0; i < n_sections; ++i) area[i] = sections[2 * i];
 
+  std::vector<double> isr(n_sections);
+  for (int i = 0; i < n_sections; ++i) isr[i] = 1.0 / (area[i] * long_stress);
   std::vector<char> blob;
   size_t o_conn = tb_push(blob, conn16), o_pairs = tb_push(blob, pairs), o_nf = tb_push(blob, nflags);
   size_t o_dp = tb_push(blob, dofpos16), o_rs = tb_push(blob, restslot), o_asm = tb_push(blob, asm_code);
   size_t o_pn = tb_push(blob, posnode), o_sn = tb_push(blob, symn), o_se = tb_push(blob, syme);
-  size_t o_ar = tb_push(blob, area);
+  // elements incident to each node (ascending element index), padded to 8 with E = "zero slot"
+  std::vector<int16_t> adj8((size_t)N * 8, (int16_t)E);
+  for (int n = 0; n < N; ++n) {
+    int c = 0;
+    for (int e = 0; e < E; ++e)
+      if (conn[2 * e] == n || conn[2 * e + 1] == n) {
+        if (c >= 8) {
+          delete t;
+          return tb_fail(TRUSS_EUNSUPPORTED, "a node joins more than 8 elements");
+        }
+        adj8[(size_t)n * 8 + c++] = (int16_t)e;
+      }
+  }
+  size_t o_ar = tb_push(blob, area), o_isr = tb_push(blob, isr);
+  size_t o_ad = tb_push(blob, adj8);
+  blob.resize((blob.size() + 15) & ~size_t(15));
   t->blob = tb_dev_alloc(blob.size());
   if (!t->blob || !tb_dev_upload(t->blob, blob.data(), blob.size())) {
     if (t->blob) tb_dev_free(t->blob);
     delete t;
     return tb_fail(TRUSS_ENOMEM, "device allocation/upload of topology tables failed");
   }
-  char *base = (char *)t->blob;
   TopoDev &D = t->dev;
   D.N = N;
   D.E = E;
@@ -347,40 +375,72 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.n_sym_elems = n_sym_elems;
   D.n_sections = n_sections;
   D.has_pairs = t->NP > 0 && 2 * t->NP == N;
-  D.conn = (const int16_t *)(base + o_conn);
-  D.pairs = (const int16_t *)(base + o_pairs);
-  D.nflags = (const uint8_t *)(base + o_nf);
-  D.dofpos = (const int16_t *)(base + o_dp);
-  D.restslot = (const int16_t *)(base + o_rs);
-  D.asm_code = (const int32_t *)(base + o_asm);
-  D.posnode = (const int16_t *)(base + o_pn);
-  D.sym_nodes = (const int16_t *)(base + o_sn);
-  D.sym_elems = (const int16_t *)(base + o_se);
-  D.sec_area = (const double *)(base + o_ar);
+  D.blob = (const char *)t->blob;
+  D.blob_bytes = (int32_t)blob.size();
+  D.f_conn = (int32_t)o_conn;
+  D.f_pairs = (int32_t)o_pairs;
+  D.f_nflags = (int32_t)o_nf;
+  D.f_dofpos = (int32_t)o_dp;
+  D.f_restslot = (int32_t)o_rs;
+  D.f_asm = (int32_t)o_asm;
+  D.f_posnode = (int32_t)o_pn;
+  D.f_symn = (int32_t)o_sn;
+  D.f_syme = (int32_t)o_se;
+  D.f_area = (int32_t)o_ar;
+  D.f_isr = (int32_t)o_isr;
+  D.f_adj8 = (int32_t)o_ad;
   D.e_mod = e_mod;
   D.long_stress = long_stress;
-  // LDS layout of one env (bytes, every array 16-byte aligned)
+  // LDS layout: [copy of the blob][env 0][env 1]...; every array 16-byte aligned
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     size_t o = off;
     off = (off + bytes + 15) & ~size_t(15);
     return (int32_t)o;
   };
-  D.o_kb = carve(sizeof(double) * (size_t)(t->n_pad + W) * W);
-  D.o_zs = carve(sizeof(double) * (t->n_pad + W));
-  D.o_dinv = carve(sizeof(double) * t->n_pad);
-  D.o_xsol = carve(sizeof(double) * (t->n_pad + 1));
-  D.o_red = carve(sizeof(double) * TRUSS_NRED * t->G);
-  D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
-  D.o_ysh = carve(sizeof(float) * N);
-  D.o_xsh = carve(sizeof(float) * N);
+  // band region; after the back substitution it is reused as the output staging area
+  {
+    size_t band = sizeof(double) * (size_t)(t->n_pad + W) * W;
+    size_t so = 0;
+    auto sub = [&](size_t bytes) {
+      size_t o = so;
+      so = (so + bytes + 15) & ~size_t(15);
+      return (int32_t)o;
+    };
+    D.so_q0 = sub(sizeof(float) * E);
+    D.so_sr = sub(sizeof(float) * E);
+    D.so_disp = sub(sizeof(float) * 2 * N);
+    D.so_mu = sub(sizeof(float) * N);
+    D.so_md = sub(sizeof(float) * N);
+    D.so_comp = sub((size_t)E);
+    D.o_kb = carve(std::max(band, so));
+  }
+  // solver scratch; before the solver the same bytes hold the per-element (k cc, k cs, k ss)
+  {
+    size_t o0 = off;
+    D.o_zs = carve(sizeof(double) * (t->n_pad + W));
+    D.o_dinv = carve(sizeof(double) * t->n_pad);
+    D.o_xsol = carve(sizeof(double) * (t->n_pad + 1));
+    D.o_red = carve(sizeof(double) * TRUSS_NRED * t->G);
+    D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
+    D.o_zring = carve(sizeof(double) * 2 * W);
+    D.o_ev = (int32_t)o0;
+    size_t need = sizeof(double) * 3 * ((size_t)E + 1);
+    if (off - o0 < need) off = (o0 + need + 15) & ~size_t(15);
+  }
+  D.o_par = carve(sizeof(double) * 8);
+  D.o_y = carve(sizeof(float) * N);
+  D.o_x = carve(sizeof(float) * N);
+  D.o_tg = carve(sizeof(float) * N);
+  D.o_geo = carve(sizeof(float) * 2 * N);
   D.o_tac = carve(sizeof(float) * 3 * N);
   D.o_sec = carve(sizeof(int32_t) * E);
   // stagger env regions across LDS banks: stride = 64 B (mod 256 B)
   size_t stride = (off + 255) & ~size_t(255);
   stride += 64;
   D.env_stride = (int32_t)stride;
-  t->lds_bytes = stride * (64 / t->G);
+  D.o_env0 = (int32_t)((blob.size() + 255) & ~size_t(255));
+  t->lds_bytes = D.o_env0 + stride * (64 / t->G);
   if (t->lds_bytes > 160 * 1024) {
     tb_dev_free(t->blob);
     delete t;

@@ -6,6 +6,7 @@
 // kernel's indexing (band offsets, window rotation, pair/symmetry tables) can be debugged in a
 // container without a GPU.  The product (mop-truss-marl_amd/truss_mi355) never loads this library;
 // truss_backend() returns "emu" so tests can tell the two apart.
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@ struct float4 {
 #define TRUSS_UNROLL
 static inline void tb_lds_add(double *p, double v) { *p += v; }
 static inline double tb_rcp(double d) { return 1.0 / d; }
+static inline double tb_rsqrt(double x) { return 1.0 / sqrt(x); }
 
 #include "../../mop-truss-marl_amd/csrc/truss_body.h"
 
@@ -34,9 +36,9 @@ static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream)
 
 #include "../../mop-truss-marl_amd/csrc/truss_host.h"
 
-template <int G, int RPL, int EPL>
+template <int G, int WL, int RPL, int EPL>
 static void emu_run(const truss_topo *t, const StepArgsDev &A) {
-  using Lane = StepLane<G, RPL, EPL>;
+  using Lane = StepLane<G, WL, RPL, EPL>;
   constexpr int W_ = Lane::W;
   const TopoDev &T = t->dev;
   const int nblocks = (A.B + Lane::EPB - 1) / Lane::EPB;
@@ -59,11 +61,10 @@ static void emu_run(const truss_topo *t, const StepArgsDev &A) {
 
 static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *) {
   const TbVariant &v = kVariants[t->variant];
-#define CASE(g, r, e) \
-  if (v.G == g && v.RPL == r && v.EPL == e) { emu_run<g, r, e>(t, A); return TRUSS_OK; }
-  CASE(8, 1, 5) CASE(8, 1, 10) CASE(8, 2, 5) CASE(8, 2, 10) CASE(16, 1, 3) CASE(16, 1, 5)
-  CASE(4, 2, 10) CASE(4, 2, 20) CASE(4, 4, 20)
-#undef CASE
+#define X(g, wl, r, e) \
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) { emu_run<g, wl, r, e>(t, A); return TRUSS_OK; }
+  TRUSS_VARIANTS(X)
+#undef X
   return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled into the emulator");
 }
 

@@ -45,6 +45,17 @@ def test_symmetric_variants_random(lib):
     pc.run_random_rollout(lib, 16, 0, 6, 2, seed=6, symmetry="large")
 
 
+@pytest.mark.parametrize("G,WL,RPL", [(8, 8, 1), (16, 8, 1), (16, 16, 1), (8, 8, 2), (16, 8, 2), (4, 4, 2)])
+def test_every_kernel_variant_emulated(lib, monkeypatch, G, WL, RPL):
+    monkeypatch.setenv("TRUSS_LANES", str(G))
+    monkeypatch.setenv("TRUSS_WLANES", str(WL))
+    monkeypatch.setenv("TRUSS_RPL", str(RPL))
+    env = pc.run_random_rollout(lib, 16, 4, 7, 2, seed=40 + G + RPL)
+    info = env.topo.solver_info(lib)
+    assert (info["lanes_per_env"], info["rows_per_lane"]) == (G, RPL)
+    env.topo.close()
+
+
 def test_threebar_analysis_only(lib):
     f = np.load(os.path.join(pc.GOLDEN, "threebar.npz"))
     topo = tm.TrussTopology(f["conn"], f["res"], np.zeros(4, np.uint8), pair=None,

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does one workgroup of truss_step_kernel spend its cycles?
+Uses the stamped build (make -C mop-truss-marl_amd/csrc diag).  Shares only -- the stamped build's
+run time is not a benchmark number."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mop-truss-marl_amd"))
+import numpy as np
+import torch
+import truss_mi355 as tm
+from truss_mi355 import synthetic
+
+NAMES = ["stage (HBM->LDS)", "decode", "sizing", "elements+assembly", "factorisation", "back-substitution",
+         "post_elements", "post_nodes", "finish"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    path = os.path.join(ROOT, "mop-truss-marl_amd", "csrc", "libtruss_mi355_diag.so")
+    lib = tm.load(path)
+    lib.dll.truss_debug_stamps.argtypes = [ctypes.c_void_p]
+    for label, topo in (("32n/80e", synthetic.bench_topology(16, 4)),):
+        batch = synthetic.random_batch(topo, B, 1)
+        env = tm.BatchedTruss(topo, B, lib=lib)
+        env.set_constants(batch["x"], batch["target"], batch["y_max"], batch["d_min"], batch["max_def"],
+                          batch["load_x"], batch["load_y"], batch["is_roof"])
+        env.set_design(batch["y"], batch["sec"])
+        env.analyze(set_normalisers=True)
+        ag, at = synthetic.random_actions(2, B, topo.N, 2)
+        G, T = torch.tensor(ag, device=env.device), torch.tensor(at, device=env.device)
+        env.rollout(G, T, 20)
+        torch.cuda.synchronize()
+        acc = np.zeros(9)
+        for _ in range(10):
+            env.rollout(G, T, 1)
+            torch.cuda.synchronize()
+            st = (ctypes.c_ulonglong * 16)()
+            lib.dll.truss_debug_stamps(st)
+            s = np.array(list(st)[:10], dtype=np.float64)
+            acc += np.diff(s)
+        acc /= 10
+        print(f"== {label} B={B}  {topo.solver_info(lib)['lanes_per_env']} lanes/env, total {acc.sum():.0f} cycles")
+        for n, c in zip(NAMES, acc):
+            print(f"   {n:22s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
