@@ -49,9 +49,12 @@
 #define TB_NO_DECODE 0x1u
 #define TB_CLAMP_INPLACE 0x2u
 
-struct alignas(16) tb_u4 {
-  uint32_t a, b, c, d;
-};
+// 16-byte unit of the HBM<->LDS copies: a native vector type (kept in VGPRs; a struct here ended up in scratch)
+#if defined(__clang__)
+typedef uint32_t tb_u4 __attribute__((ext_vector_type(4)));
+#else
+typedef uint32_t tb_u4 __attribute__((vector_size(16)));
+#endif
 
 // All topology tables live in ONE blob (global memory); f_* are byte offsets into it.  The step
 // kernel copies the blob to the start of its LDS and reads the copy; the observation kernel reads
