@@ -101,42 +101,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import truss_mi355 as tm
-    from truss_mi355 import synthetic
+    from truss_mi355 import synthetic, distributed
     lib = tm.load()                      # raises if the HIP extension is missing
     topo = synthetic.bench_topology(NUM_X, N_EXTRA)
     B = args.envs
-    batch = synthetic.random_batch(topo, B, seed=1234 + 7919 * rank)
-    env = tm.BatchedTruss(topo, B, device=dev, lib=lib)
-    env.set_constants(batch["x"], batch["target"], batch["y_max"], batch["d_min"], batch["max_def"], batch["load_x"],
-                      batch["load_y"], batch["is_roof"])
-    env.set_design(batch["y"], batch["sec"])
-    env.analyze(set_normalisers=True)    # reset path: int_obj1/int_obj2
-    ag, at = synthetic.random_actions(N_ACTION_SETS, B, topo.N, seed=4321 + rank)
-    G = torch.tensor(ag, device=dev)
-    T = torch.tensor(at, device=dev)
-    torch.cuda.synchronize()
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    env.rollout(G, T, args.warmup)
-    sync_all()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                          # same stream the kernels are launched on
-    env.rollout(G, T, args.steps)
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sync_all()
-    dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    env, G, T, _ = distributed.make_rank_env(topo, B, rank, device=dev, lib=lib, seed=1234,
+                                             n_action_sets=N_ACTION_SETS)
+    elapsed, dev_ms = distributed.timed_rollout(env, G, T, args.steps, args.warmup, dist)
     st = int(env.status.sum().item())
 
     extras = {}
@@ -193,7 +164,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+                # separate passes): profiles/r1/03_pmc_hbm_traffic.json (valid for envs=4096, 32n/80e)
+                "traffic": 13381632 if (B == 4096 and topo.N == 32 and topo.E == 80) else None,
                 "kernel": "truss_step_kernel", "kernel_us": kern_s * 1e6,
                 "bytes_per_launch": per_step_bytes,
             },

@@ -34,6 +34,9 @@
 #include <stdint.h>
 #include <math.h>
 
+#ifndef TB_SCHED_FENCE
+#define TB_SCHED_FENCE()  // device: __builtin_amdgcn_sched_barrier(0); pins hand-placed prefetches
+#endif
 #ifndef TRUSS_HD
 #error "define TRUSS_HD (e.g. __device__ __forceinline__) before including truss_body.h"
 #endif
@@ -599,16 +602,41 @@ struct StepLane {
     }
   }
 
-  // x_k = (z_k - sum_m A[k+m,k] x_{k+m}) / d_k, every lane of the group redundantly
-  TRUSS_HD void backsub_step(const TopoDev &T, int k, int kk) {
-    const double *K = kb(T);
-    double acc = zs(T)[k];
+  // x_k = (z_k - sum_m A[k+m,k] x_{k+m}) / d_k, every lane of the group redundantly.
+  //  * the coefficients of step k-1 are fetched from LDS (into the other register slot) BEFORE step k's
+  //    arithmetic, so the LDS latency overlaps the FMA chain instead of preceding it;
+  //  * the terms are accumulated oldest-x first in two partial sums: only one fma and one multiply
+  //    depend on the x_{k+1} the previous step has just produced.
+  double bc[2][W], bz[2], bd[2];
+  TRUSS_HD void backsub_prefetch(const TopoDev &T, int k, int slot) {
+    const double *K = kb(T) + (k < 0 ? 0 : k) * W;
 #pragma unroll
-    for (int j = 0; j < W; ++j)
-      if (j != kk) acc = fma(-K[k * W + j], xs[j], acc);
-    double xk = acc * dinv(T)[k];
+    for (int j = 0; j < W; ++j) bc[slot][j] = K[j];
+    bz[slot] = zs(T)[k < 0 ? 0 : k];
+    bd[slot] = dinv(T)[k < 0 ? 0 : k];
+  }
+  TRUSS_HD void backsub_step(const TopoDev &T, int k, int kk) {
+    const int slot = kk & 1;
+    backsub_prefetch(T, k - 1, slot ^ 1);
+    TB_SCHED_FENCE();
+    double acc0 = bz[slot], acc1 = 0.0;
+#pragma unroll
+    for (int m = W - 1; m >= 2; --m) {  // rows k+m, m = W-1 .. 2 (older solutions)
+      const int j = (kk + m) % W;
+      if (m & 1) acc1 = fma(-bc[slot][j], xs[j], acc1);
+      else acc0 = fma(-bc[slot][j], xs[j], acc0);
+    }
+    const int jn = (kk + 1) % W;        // row k+1: the newest solution
+    double acc = fma(-bc[slot][jn], xs[jn], acc0 + acc1);
+    double xk = acc * bd[slot];
     xs[kk] = xk;
-    xsol(T)[k] = xk;
+  }
+  // after a block of W steps: xs[j] is x of row kb + j.  Stored once per block so the LDS loads of the
+  // next steps are not fenced behind a may-alias store after every step.
+  TRUSS_HD void backsub_flush(const TopoDev &T, int kb) {
+    double *XS = xsol(T) + kb;
+#pragma unroll
+    for (int j = 0; j < W; ++j) XS[j] = xs[j];
   }
 
   // Output staging: after the back substitution the band region is dead; the per-env result rows are
@@ -803,9 +831,11 @@ struct StepLane {
   }                                                                                 \
   BAR();                                                                            \
   TRUSS_ST(5);                                                                      \
+  PH_NS(backsub_prefetch(T, (T).n_pad - 1, (W_ - 1) & 1));                          \
   for (int kb_ = (T).n_pad - W_; kb_ >= 0; kb_ -= W_) {                             \
     TRUSS_UNROLL                                                                    \
     for (int kk_ = W_ - 1; kk_ >= 0; --kk_) { PH_NS(backsub_step(T, kb_ + kk_, kk_)); } \
+    PH_NS(backsub_flush(T, kb_));                                                   \
   }                                                                                 \
   BAR();                                                                            \
   TRUSS_ST(6);                                                                      \

@@ -14,6 +14,7 @@
 
 #define TRUSS_HD __device__ __forceinline__
 #define TRUSS_UNROLL _Pragma("unroll")
+#define TB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // LDS float64 scatter-add (ds_add_f64 on gfx950)
 __device__ __forceinline__ void tb_lds_add(double *p, double v) { unsafeAtomicAdd(p, v); }
@@ -54,11 +55,21 @@ __global__ __launch_bounds__(64) void truss_step_kernel(const TopoDev T, const S
   StepLane<G, WL, RPL, EPL> ln;
   ln.init(threadIdx.x, blockIdx.x, T, A, smem);
   constexpr int W_ = StepLane<G, WL, RPL, EPL>::W;
+  // The workgroup IS one wavefront: its LDS instructions execute in issue order, so a later ds_read
+  // sees an earlier ds_write of any lane without waiting for it.  A wavefront-scope fence plus
+  // wave_barrier keeps the compiler from reordering across a phase boundary and emits no s_waitcnt /
+  // s_barrier (a __syncthreads() here costs a full LDS round trip per pivot of the factorisation).
+#define TB_WAVE_SYNC()                                    \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
 #define PH(call) \
   ln.call;       \
-  __syncthreads()
+  TB_WAVE_SYNC()
 #define PH_NS(call) ln.call
-#define BAR() __syncthreads()
+#define BAR() TB_WAVE_SYNC()
   TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
 #undef PH
 #undef PH_NS

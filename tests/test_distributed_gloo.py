@@ -1,0 +1,68 @@
+"""N>1 path on CPU: two gloo ranks, each stepping its own shard through the lane emulator; checks that
+(a) the shards are what single-process runs of the same seeds produce, (b) the barrier / MAX-reduce
+plumbing bench.py relies on works, (c) no rank depends on another rank's data."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import parity_common as pc
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, lib_path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import truss_mi355 as tm
+    from truss_mi355 import synthetic, distributed
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = tm.load(lib_path)
+    topo = synthetic.bench_topology(16, 4)
+    env, G, T, _ = distributed.make_rank_env(topo, 24, rank, lib=lib, seed=1234, n_action_sets=3)
+    elapsed, dev_ms = distributed.timed_rollout(env, G, T, steps=3, warmup=1, dist=dist)
+    total = distributed.global_checksum(env, dist)
+    mine = distributed.global_checksum(env, None)
+    gathered = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, torch.tensor(mine))
+    if rank == 0:
+        out.put((elapsed, dev_ms, total.tolist(), [g.tolist() for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_rollout():
+    lib_path = pc.build_emu()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, lib_path, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    elapsed, dev_ms, total, per_rank = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert elapsed > 0 and dev_ms is None
+    # single-process reference of each shard
+    import truss_mi355 as tm
+    from truss_mi355 import synthetic, distributed
+    lib = tm.load(lib_path)
+    topo = synthetic.bench_topology(16, 4)
+    want = []
+    for r in range(2):
+        env, G, T, _ = distributed.make_rank_env(topo, 24, r, lib=lib, seed=1234, n_action_sets=3)
+        env.rollout(G, T, 1)
+        env.rollout(G, T, 3)
+        want.append(distributed.global_checksum(env, None))
+    np.testing.assert_array_equal(np.array(per_rank), np.array(want))
+    np.testing.assert_allclose(np.array(total), np.array(want).sum(axis=0), rtol=1e-15)
+    assert not np.array_equal(want[0], want[1])      # the shards really are different envs
