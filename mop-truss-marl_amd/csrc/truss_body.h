@@ -55,15 +55,30 @@
 // 16-byte unit of the HBM<->LDS copies: a native vector type (kept in VGPRs; a struct here ended up in scratch)
 #if defined(__clang__)
 typedef uint32_t tb_u4 __attribute__((ext_vector_type(4)));
+typedef double tb_d2 __attribute__((ext_vector_type(2)));
 #else
 typedef uint32_t tb_u4 __attribute__((vector_size(16)));
+typedef double tb_d2 __attribute__((vector_size(16)));
 #endif
+// 16-byte LDS row access (ds_read_b128 / ds_write_b128): band rows and rings are 16-byte aligned
+TRUSS_HD void tb_ld_row(const double *p, double *dst, int n2) {
+  const tb_d2 *q = (const tb_d2 *)__builtin_assume_aligned(p, 16);
+  for (int i = 0; i < n2; ++i) {
+    tb_d2 v = q[i];
+    dst[2 * i] = v[0];
+    dst[2 * i + 1] = v[1];
+  }
+}
 
 // All topology tables live in ONE blob (global memory); f_* are byte offsets into it.  The step
 // kernel copies the blob to the start of its LDS and reads the copy; the observation kernel reads
 // the global blob directly.
 struct TopoDev {
   int32_t N, E, NP, ndof, n_pad, n_rest, n_sym_nodes, n_sym_elems, n_sections, has_pairs;
+  // solver geometry.  One team (NT = 1): KA = n_pad pivots top-down, no middle.  Two teams (NT = 2):
+  // team A eliminates positions [0, KA), team B the reversed positions [0, KA) (= original n-1 .. n-KA),
+  // the `mid` = n - 2 KA <= W rows in between are merged into team A's window and finished there.
+  int32_t nteams, KA, mid, rowsA, rowsB, zlen, dlen, zslot;
   const char *blob;
   int32_t blob_bytes;  // multiple of 16
   int32_t f_conn;      // int16 [E][2]
@@ -71,7 +86,8 @@ struct TopoDev {
   int32_t f_nflags;    // uint8 [N]
   int32_t f_dofpos;    // int16 [N][2]   solver position of (node, comp) or -1 when restrained
   int32_t f_restslot;  // int16 [N][2]   reaction slot (reference order nsc-ndof-1) or -1
-  int32_t f_asm;       // int32 [E][10]  (band offset << 3) | (type << 1) | negate, or -1
+  int32_t f_asm;       // int16 [E][10]  (band offset << 3) | (type << 1) | negate, or -1
+  int32_t f_diagoff;   // int16 [N][3]   band offsets of (x,x), (y,y), (x,y) of the node block, or -1
   int32_t f_posnode;   // int16 [n_pad]  node*2+comp at solver position, -1 = padding row
   int32_t f_symn;      // int16 [n][2]   (dst, src)
   int32_t f_syme;      // int16 [n][2]
@@ -81,7 +97,7 @@ struct TopoDev {
   double e_mod, long_stress;
   // LDS layout of the step kernel: [blob copy][env 0][env 1]...; o_* are byte offsets inside one env
   int32_t o_env0, env_stride;
-  int32_t o_kb, o_zs, o_dinv, o_xsol, o_red, o_rbuf, o_par, o_y, o_x, o_tg, o_geo, o_tac, o_sec, o_ev, o_zring;
+  int32_t o_kb, o_zs, o_dinv, o_xsol, o_red, o_rbuf, o_par, o_y, o_x, o_tg, o_geo, o_tac, o_sec, o_ev, o_zring, o_mrg;
   // output staging rows inside the (dead) band region, each 16-byte aligned
   int32_t so_q0, so_sr, so_disp, so_mu, so_md, so_comp;
 };
@@ -123,8 +139,10 @@ struct StepLane {
   static constexpr int W = WL * RPL;
   static constexpr int EPB = 64 / G;  // envs per wave
   static constexpr int NDEG = 8;      // unrolled node-degree bound of the diagonal gather
+  static constexpr int NT = G / WL;   // solver teams per env (1, or 2 = two-sided elimination)
 
-  int lane, g, gs, env, envc;
+  int lane, g, gs, team, env, envc;
+  double *Kt, *Zt, *Dt, *ZRt;  // this lane's team: band rows, z / P vector, 1/d, broadcast ring
   bool active;
   const char *TB;  // LDS copy of the topology blob
   char *L;         // this env's LDS region
@@ -163,7 +181,8 @@ struct StepLane {
   TRUSS_HD const uint8_t *t_nflags(const TopoDev &T) const { return TB_TAB(uint8_t, TB, T.f_nflags); }
   TRUSS_HD const int16_t *t_dofpos(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_dofpos); }
   TRUSS_HD const int16_t *t_restslot(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_restslot); }
-  TRUSS_HD const int32_t *t_asm(const TopoDev &T) const { return TB_TAB(int32_t, TB, T.f_asm); }
+  TRUSS_HD const int16_t *t_asm(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_asm); }
+  TRUSS_HD const int16_t *t_diagoff(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_diagoff); }
   TRUSS_HD const int16_t *t_posnode(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_posnode); }
   TRUSS_HD const int16_t *t_symn(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_symn); }
   TRUSS_HD const int16_t *t_syme(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_syme); }
@@ -176,12 +195,17 @@ struct StepLane {
     lane = lane_;
     g = lane % G;
     gs = g % WL;
+    team = T.nteams == 2 ? g / WL : 0;  // one team: lanes beyond WL mirror lanes 0..WL-1
     int grp = lane / G;
     env = block * EPB + grp;
     active = env < A.B;
     envc = active ? env : A.B - 1;
     TB = lds;
     L = lds + T.o_env0 + (size_t)grp * T.env_stride;
+    Kt = (double *)(L + T.o_kb) + team * T.rowsA * W;
+    Zt = (double *)(L + T.o_zs) + team * T.zlen;
+    Dt = (double *)(L + T.o_dinv) + team * T.dlen;
+    ZRt = (double *)(L + T.o_zring) + team * 2 * W;
     bad = 0;
     p_vol = p_dt = p_en = 0.0;
     p_c1 = p_c2 = 0.0f;
@@ -283,7 +307,7 @@ struct StepLane {
     {
       tb_u4 *K4 = (tb_u4 *)kb(T);
       const tb_u4 z = {0u, 0u, 0u, 0u};
-      const int tot4 = ((T.n_pad + W) * W) >> 1;
+      const int tot4 = ((T.rowsA + T.rowsB) * W) >> 1;
       for (int i = g; i < tot4; i += G) K4[i] = z;
     }
   }
@@ -438,13 +462,23 @@ struct StepLane {
     }
   }
 
+  // load on the DOF at ORIGINAL solver position r (0 for padding / out of range)
   TRUSS_HD double load_at(const TopoDev &T, int r) const {
-    if (r >= T.n_pad) return 0.0;
+    if (r < 0 || r >= T.ndof) return 0.0;
     int nd = t_posnode(T)[r];
     if (nd < 0) return 0.0;
     int fl = t_nflags(T)[nd >> 1] & (is_roof ? TF_LOAD_ROOF : TF_LOAD_BRIDGE);
     if (!fl) return 0.0;
     return (nd & 1) ? load_y : load_x;
+  }
+  // original solver position of team-frame position p (team B works on the reversed system)
+  TRUSS_HD int orig_pos(const TopoDev &T, int tm, int p) const { return tm ? T.ndof - 1 - p : p; }
+  // right-hand side a team holds for its frame position p: team A owns its part and the middle rows,
+  // team B only its own part (its middle rows start from zero and only collect Schur updates)
+  TRUSS_HD double team_load(const TopoDev &T, int tm, int p) const {
+    if (T.nteams == 1) return load_at(T, p);
+    if (tm == 0) return p < T.ndof - T.KA ? load_at(T, p) : 0.0;
+    return p < T.KA ? load_at(T, T.ndof - 1 - p) : 0.0;
   }
 
   // ---- phase 4: element stiffness + scatter-add into the LDS band; load vector ----
@@ -484,7 +518,7 @@ struct StepLane {
     // pass 2 (FEM_2Dtruss.py:320-324 restricted to the lower band, without atomics): the four
     // off-diagonal entries of an element belong to that element alone -> plain stores; the element's
     // (k cc, k cs, k ss) go to LDS for the node-diagonal gather of phase_assemble_nodes.
-    const int32_t *AC = t_asm(T);
+    const int16_t *AC = t_asm(T);
     double *EV = evsh(T);
     if (g == 0) EV[3 * T.E] = EV[3 * T.E + 1] = EV[3 * T.E + 2] = 0.0;  // slot the padded adjacency points at
 #pragma unroll
@@ -494,7 +528,7 @@ struct StepLane {
         EV[3 * e + 0] = kcc[i];
         EV[3 * e + 1] = kcs[i];
         EV[3 * e + 2] = kss[i];
-        const int32_t *code = AC + e * 10 + 6;
+        const int16_t *code = AC + e * 10 + 6;
         const int c0 = code[0], c1 = code[1], c2 = code[2], c3 = code[3];
         if (c0 >= 0) K[c0 >> 3] = -kcc[i];
         if (c1 >= 0) K[c1 >> 3] = -kss[i];
@@ -509,7 +543,7 @@ struct StepLane {
   // code and its LDS reads overlap.
   TRUSS_HD void phase_assemble_nodes(const TopoDev &T) {
     const double *EV = evsh(T);
-    const int16_t *AD = t_adj8(T), *DP = t_dofpos(T);
+    const int16_t *AD = t_adj8(T), *DO = t_diagoff(T);
     double *K = kb(T);
     for (int n = g; n < T.N; n += G) {
       double cc = 0.0, cs = 0.0, ss = 0.0;
@@ -520,36 +554,42 @@ struct StepLane {
         cs += EV[3 * e + 1];
         ss += EV[3 * e + 2];
       }
-      const int px = DP[2 * n], py = DP[2 * n + 1];
-      if (px >= 0) K[px * W] = cc;
-      if (py >= 0) K[py * W] = ss;
-      if (px >= 0 && py >= 0) {
-        const int hi = px > py ? px : py, lo = px > py ? py : px;
-        K[hi * W + (hi - lo)] = cs;
-      }
+      const int o0 = DO[3 * n], o1 = DO[3 * n + 1], o2 = DO[3 * n + 2];
+      if (o0 >= 0) K[o0] = cc;
+      if (o1 >= 0) K[o1] = ss;
+      if (o2 >= 0) K[o2] = cs;
     }
-    for (int r = T.ndof + g; r < T.n_pad + W; r += G) K[r * W] = 1.0;  // padding rows: identity
+    // identity rows: team A beyond its part + middle; team B beyond the middle (its middle rows keep a
+    // zero diagonal: they are never pivots of team B)
+    const int idA = T.nteams == 1 ? T.ndof : T.ndof - T.KA;
+    for (int r = idA + g; r < T.rowsA; r += G) K[r * W] = 1.0;
+    for (int r = T.KA + T.mid + g; r < T.rowsB; r += G) K[(T.rowsA + r) * W] = 1.0;
   }
 
   // ---- phase 5b: the element-value buffer is dead; its bytes become the solver scratch ----
   TRUSS_HD void solver_scratch_init(const TopoDev &T) {
     double *Z = zs(T);
-    for (int r = g; r < T.n_pad + W; r += G) Z[r] = load_at(T, r);  // load vector P by solver position
+    for (int r = g; r < T.zlen * T.nteams; r += G) {
+      const int tm = r >= T.zlen, p = tm ? r - T.zlen : r;
+      Z[r] = team_load(T, tm, p);
+    }
+    double *XS = xsol(T);
+    for (int r = g; r <= T.zslot; r += G) XS[r] = 0.0;  // also the zero slot the restrained DOFs read
     double *RB = rbuf(T);
     for (int i = g; i < T.n_rest; i += G) RB[i] = 0.0;
-    if (g == 0) xsol(T)[T.n_pad] = 0.0;
   }
 
   // ---- solver -------------------------------------------------------------------------------
+  // Every routine below works in the lane's TEAM FRAME (Kt/Zt/Dt/ZRt): team A on the system as
+  // ordered by the host, team B (only when NT == 2) on the same system with rows and columns
+  // reversed.  The code is identical for both; only the LDS bases differ.
   TRUSS_HD void solver_init(const TopoDev &T) {
-    const double *K = kb(T);
-    const double *Z = zs(T);
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
       int r = gs + WL * s;
 #pragma unroll
-      for (int c = 0; c < W; ++c) R[s][c] = (c <= r) ? K[r * W + (r - c)] : K[c * W + (c - r)];
-      rhs[s] = Z[r];
+      for (int c = 0; c < W; ++c) R[s][c] = (c <= r) ? Kt[r * W + (r - c)] : Kt[c * W + (c - r)];
+      rhs[s] = Zt[r];
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) xs[j] = 0.0;
@@ -558,26 +598,27 @@ struct StepLane {
   // post this lane's entries of pivot column k (kk = k mod W, compile-time after unrolling) and its
   // right-hand sides; no predication: mirror lanes store the same values to the same addresses
   TRUSS_HD void pivot_write(const TopoDev &T, int k, int kk) {
-    double *K = kb(T);
-    double *ZR = zring(T) + (k & 1) * W;
+    double *ZR = ZRt + (k & 1) * W;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
-      K[k * W + gs + WL * s] = R[s][kk];
+      Kt[k * W + gs + WL * s] = R[s][kk];
       ZR[gs + WL * s] = rhs[s];
     }
   }
 
   TRUSS_HD void pivot_update(const TopoDev &T, int k, int kk) {
-    const double *K = kb(T);
     double col[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) col[j] = K[k * W + j];
-    const double zk = zring(T)[(k & 1) * W + kk];
+    for (int i = 0; i < W / 2; ++i) {
+      tb_d2 v = ((const tb_d2 *)__builtin_assume_aligned(Kt + k * W, 16))[i];
+      col[2 * i] = v[0];
+      col[2 * i + 1] = v[1];
+    }
+    const double zk = ZRt[(k & 1) * W + kk];
     const double d = col[kk];
-    if (!(d > 0.0)) bad = 1;
-    const double inv = tb_rcp(d);
-    dinv(T)[k] = inv;  // every lane stores the same value
-    zs(T)[k] = zk;     // z_k replaces P_k (P_k was consumed when row k entered the window)
+    const double inv = tb_rcp(d);  // d <= 0 / NaN is detected after the loop (pivot_check), off the chain
+    if (k < T.dlen) Dt[k] = inv;  // every lane of the team stores the same value
+    Zt[k] = zk;            // z_k replaces P_k (P_k was consumed when row k entered the window)
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
       double l = R[s][kk] * inv;
@@ -588,7 +629,7 @@ struct StepLane {
     }
     // the window slides: column k leaves, column k+W enters; the pivot row's lane adopts row k+W
     const int rn = k + W;
-    const double *Kn = K + rn * W;
+    const double *Kn = Kt + rn * W;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
       int o = (gs + WL * s - kk + W) % W;  // this row is k+o; it needs K[k+W][k+o] = band entry W-o
@@ -596,24 +637,78 @@ struct StepLane {
     }
     if (gs == kk % WL) {
       const int sp = kk / WL;
+      double nr[W];
 #pragma unroll
-      for (int j = 1; j < W; ++j) R[sp][(kk + j) % W] = Kn[W - j];
-      rhs[sp] = zs(T)[rn];
+      for (int i = 0; i < W / 2; ++i) {
+        tb_d2 v = ((const tb_d2 *)__builtin_assume_aligned(Kn, 16))[i];
+        nr[2 * i] = v[0];
+        nr[2 * i + 1] = v[1];
+      }
+#pragma unroll
+      for (int j = 1; j < W; ++j) R[sp][(kk + j) % W] = nr[W - j];
+      rhs[sp] = Zt[rn];
     }
   }
 
-  // x_k = (z_k - sum_m A[k+m,k] x_{k+m}) / d_k, every lane of the group redundantly.
+  // K not SPD <=> some pivot d <= 0 (or NaN): then 1/d is not a positive finite number.  Each lane scans a
+  // share of its team's stored reciprocals once, after the factorisation.  (Team B's idle pivots k >= KA
+  // are not looked at.)
+  TRUSS_HD void pivot_check(const TopoDev &T) {
+    const int lim = (T.nteams == 2 && team == 1) ? T.KA : (T.nteams == 2 ? T.KA + W : T.KA);
+    for (int k = gs; k < lim; k += WL) {
+      const double v = Dt[k];
+      if (!(v > 0.0) || !(v < 1.7e308)) bad = 1;
+    }
+  }
+
+  // ---- two-sided elimination: fold team B's window (Schur updates of the middle rows) into team A's
+  // frame row held by this lane's window slot (RPL == 1): KA + ((gs - KA) mod W)
+  TRUSS_HD int win_row(const TopoDev &T, int slot) const { return T.KA + ((slot - T.KA % W + W) % W); }
+  TRUSS_HD void merge_post(const TopoDev &T) {
+    if (team == 1) {
+      double *M = (double *)(L + T.o_mrg);
+#pragma unroll
+      for (int j = 0; j < W; ++j) M[gs * W + j] = R[0][j];
+      M[W * W + gs] = rhs[0];
+    }
+  }
+  TRUSS_HD void merge_take(const TopoDev &T) {
+    if (team == 0) {
+      const double *M = (const double *)(L + T.o_mrg);
+      const int lim = T.ndof - T.KA;           // frame-A rows/cols >= lim belong to team B's part
+      const int p = win_row(T, gs);
+      const int pb = T.ndof - 1 - p;           // the same DOF in team B's frame
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const int c = win_row(T, j);
+        const int cb = T.ndof - 1 - c;
+        const bool ok = p < lim && c < lim;
+        const double add = M[ok ? (pb % W) * W + (cb % W) : 0];
+        R[0][j] += ok ? add : 0.0;
+      }
+      const double az = M[W * W + (p < lim ? pb % W : 0)];
+      rhs[0] += p < lim ? az : 0.0;
+    }
+  }
+
+  // back substitution, every lane of the team redundantly:
+  //   x_k = (z_k - sum_m A[k+m,k] x_{k+m}) / d_k
   //  * the coefficients of step k-1 are fetched from LDS (into the other register slot) BEFORE step k's
   //    arithmetic, so the LDS latency overlaps the FMA chain instead of preceding it;
   //  * the terms are accumulated oldest-x first in two partial sums: only one fma and one multiply
   //    depend on the x_{k+1} the previous step has just produced.
   double bc[2][W], bz[2], bd[2];
   TRUSS_HD void backsub_prefetch(const TopoDev &T, int k, int slot) {
-    const double *K = kb(T) + (k < 0 ? 0 : k) * W;
+    const int kc = k < 0 ? 0 : k;
+    const tb_d2 *K2 = (const tb_d2 *)__builtin_assume_aligned(Kt + kc * W, 16);
 #pragma unroll
-    for (int j = 0; j < W; ++j) bc[slot][j] = K[j];
-    bz[slot] = zs(T)[k < 0 ? 0 : k];
-    bd[slot] = dinv(T)[k < 0 ? 0 : k];
+    for (int i = 0; i < W / 2; ++i) {
+      tb_d2 v = K2[i];
+      bc[slot][2 * i] = v[0];
+      bc[slot][2 * i + 1] = v[1];
+    }
+    bz[slot] = Zt[kc];
+    bd[slot] = Dt[kc < T.dlen ? kc : 0];
   }
   TRUSS_HD void backsub_step(const TopoDev &T, int k, int kk) {
     const int slot = kk & 1;
@@ -631,12 +726,38 @@ struct StepLane {
     double xk = acc * bd[slot];
     xs[kk] = xk;
   }
-  // after a block of W steps: xs[j] is x of row kb + j.  Stored once per block so the LDS loads of the
-  // next steps are not fenced behind a may-alias store after every step.
+  // after a block of W steps: xs[j] is x of team-frame row kb + j.  Stored once per block so the LDS
+  // loads of the next steps are not fenced behind a may-alias store after every step.  Team B's slots
+  // of the middle block (kb + j >= KA) were solved by team A and are not written by team B.
+  TRUSS_HD bool owns_row(const TopoDev &T, int p) const {
+    if (T.nteams == 1) return true;
+    return team == 0 ? p < T.ndof - T.KA : p < T.KA;   // A: its part + the middle; B: its part
+  }
   TRUSS_HD void backsub_flush(const TopoDev &T, int kb) {
-    double *XS = xsol(T) + kb;
+    double *XS = xsol(T);
 #pragma unroll
-    for (int j = 0; j < W; ++j) XS[j] = xs[j];
+    for (int j = 0; j < W; ++j) {
+      const int p = kb + j;
+      if (owns_row(T, p)) XS[orig_pos(T, team, p)] = xs[j];
+    }
+  }
+  // mid-block variant used right after the middle block: slot j holds the window row win_row(j)
+  TRUSS_HD void backsub_flush_mid(const TopoDev &T) {
+    double *XS = xsol(T);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int p = win_row(T, j);
+      if (team == 0 && owns_row(T, p)) XS[p] = xs[j];
+    }
+  }
+  // team B picks up the middle solutions (in its own frame) before it continues outwards
+  TRUSS_HD void backsub_reload(const TopoDev &T) {
+    const double *XS = xsol(T);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int o = orig_pos(T, team, win_row(T, j));
+      xs[j] = XS[(o >= 0 && o < T.ndof) ? o : T.zslot];
+    }
   }
 
   // Output staging: after the back substitution the band region is dead; the per-env result rows are
@@ -654,7 +775,7 @@ struct StepLane {
     const double *XS = xsol(T);
     const int16_t *CN = t_conn(T), *DP = t_dofpos(T), *RS = t_restslot(T);
     const size_t be = (size_t)envc * T.E;
-    const int zslot = T.n_pad;
+    const int zslot = T.zslot;
     float *Q = oq0(T), *SR = osr(T);
     uint8_t *CP = ocomp(T);
 #pragma unroll
@@ -696,7 +817,7 @@ struct StepLane {
     const int16_t *DP = t_dofpos(T), *PR = t_pairs(T);
     const uint8_t *NF = t_nflags(T);
     const size_t bn = (size_t)envc * T.N;
-    const int zslot = T.n_pad;
+    const int zslot = T.zslot;
     float *DS = odisp(T), *MU = omu(T), *MD = omd(T);
     for (int n = g; n < T.N; n += G) {
       int px = DP[2 * n], py = DP[2 * n + 1];
@@ -723,13 +844,14 @@ struct StepLane {
       }
     }
     if (A.energy)
-      for (int r = g; r < T.n_pad; r += G) p_en += XS[r] * load_at(T, r);
+      for (int r = g; r < T.ndof; r += G) p_en += XS[r] * load_at(T, r);
     double *RD = red(T);
     RD[0 * G + g] = p_vol;
     RD[1 * G + g] = p_dt;
     RD[2 * G + g] = (double)p_c1;
     RD[3 * G + g] = (double)p_c2;
     RD[4 * G + g] = p_en;
+    RD[5 * G + g] = (double)bad;
   }
 
   // copy one result row LDS -> HBM with the env's own G lanes (16-byte stores when possible)
@@ -777,6 +899,7 @@ struct StepLane {
       c1 = fmaxf(c1, (float)RD[2 * G + j]);
       c2 = fmaxf(c2, (float)RD[3 * G + j]);
       en += RD[4 * G + j];
+      if (RD[5 * G + j] != 0.0) bad = 1;
     }
     float obj1 = (float)vol, obj2 = (float)dt;
     float *pt = A.point + (size_t)env * 4;
@@ -822,20 +945,58 @@ struct StepLane {
   PH(solver_scratch_init(T));                                                       \
   TRUSS_ST(4);                                                                      \
   PH(solver_init(T));                                                               \
-  for (int kb_ = 0; kb_ < (T).n_pad; kb_ += W_) {                                   \
-    TRUSS_UNROLL                                                                    \
-    for (int kk_ = 0; kk_ < W_; ++kk_) {                                            \
-      PH(pivot_write(T, kb_ + kk_, kk_));                                           \
-      PH_NS(pivot_update(T, kb_ + kk_, kk_));                                       \
+  {                                                                                 \
+    /* Factorisation.  Blocks of W pivots that lie entirely inside a team's own part run the clean,  \
+       unguarded body; only the (at most two) blocks around the merge point carry guards. */         \
+    const int kend_ = (T).nteams == 2 ? (T).KA + W_ : (T).KA;                       \
+    int kb_ = 0;                                                                    \
+    for (; kb_ + W_ <= (T).KA; kb_ += W_) {                                         \
+      TRUSS_UNROLL                                                                  \
+      for (int kk_ = 0; kk_ < W_; ++kk_) {                                          \
+        PH(pivot_write(T, kb_ + kk_, kk_));                                         \
+        PH_NS(pivot_update(T, kb_ + kk_, kk_));                                     \
+      }                                                                             \
     }                                                                               \
-  }                                                                                 \
-  BAR();                                                                            \
-  TRUSS_ST(5);                                                                      \
-  PH_NS(backsub_prefetch(T, (T).n_pad - 1, (W_ - 1) & 1));                          \
-  for (int kb_ = (T).n_pad - W_; kb_ >= 0; kb_ -= W_) {                             \
-    TRUSS_UNROLL                                                                    \
-    for (int kk_ = W_ - 1; kk_ >= 0; --kk_) { PH_NS(backsub_step(T, kb_ + kk_, kk_)); } \
-    PH_NS(backsub_flush(T, kb_));                                                   \
+    for (; kb_ < kend_; kb_ += W_) {                                                \
+      TRUSS_UNROLL                                                                  \
+      for (int kk_ = 0; kk_ < W_; ++kk_) {                                          \
+        if (kb_ + kk_ < kend_) {                                                    \
+          if (kb_ + kk_ == (T).KA) {                                                \
+            PH(merge_post(T));                                                      \
+            PH(merge_take(T));                                                      \
+          }                                                                         \
+          PH(pivot_write(T, kb_ + kk_, kk_));                                       \
+          PH_NS(pivot_update(T, kb_ + kk_, kk_));                                   \
+        }                                                                           \
+      }                                                                             \
+    }                                                                               \
+    BAR();                                                                          \
+    PH_NS(pivot_check(T));                                                          \
+    TRUSS_ST(5);                                                                    \
+    /* Back substitution, top block first.  Special (guarded) blocks: those that contain the first step \
+       kend-1 or the hand-over step KA-1 of the two-sided scheme; everything below runs clean. */    \
+    kb_ = ((kend_ - 1) / W_) * W_;                                                  \
+    if ((T).nteams == 1) { PH_NS(backsub_prefetch(T, kend_ - 1, (W_ - 1) & 1)); }   \
+    for (; (T).nteams == 2 && kb_ >= 0 && kb_ + W_ - 1 >= (T).KA - 1; kb_ -= W_) {  \
+      TRUSS_UNROLL                                                                  \
+      for (int kk_ = W_ - 1; kk_ >= 0; --kk_) {                                     \
+        if (kb_ + kk_ < kend_) {                                                    \
+          if (kb_ + kk_ == (T).KA - 1) {                                            \
+            PH_NS(backsub_flush_mid(T));                                            \
+            BAR();                                                                  \
+            PH_NS(backsub_reload(T));                                               \
+          }                                                                         \
+          if (kb_ + kk_ == kend_ - 1) { PH_NS(backsub_prefetch(T, kb_ + kk_, kk_ & 1)); } \
+          PH_NS(backsub_step(T, kb_ + kk_, kk_));                                   \
+        }                                                                           \
+      }                                                                             \
+      PH_NS(backsub_flush(T, kb_));                                                 \
+    }                                                                               \
+    for (; kb_ >= 0; kb_ -= W_) {                                                   \
+      TRUSS_UNROLL                                                                  \
+      for (int kk_ = W_ - 1; kk_ >= 0; --kk_) { PH_NS(backsub_step(T, kb_ + kk_, kk_)); } \
+      PH_NS(backsub_flush(T, kb_));                                                 \
+    }                                                                               \
   }                                                                                 \
   BAR();                                                                            \
   TRUSS_ST(6);                                                                      \

@@ -39,7 +39,8 @@ __device__ unsigned long long g_truss_stamps[16];
   } while (0)
 #endif
 
-// 1/sqrt(x): v_rsq_f64 seed + two Newton steps
+// 1/sqrt(x): v_rsq_f64 seed (measured 5.2e-8 relative on gfx950, tools/rcp_accuracy.hip) + two Newton
+// steps (one step leaves 4e-15)
 __device__ __forceinline__ double tb_rsqrt(double x) {
   double r = __builtin_amdgcn_rsq(x);
   r = r * fma(-0.5 * x, r * r, 1.5);

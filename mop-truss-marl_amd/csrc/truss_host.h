@@ -266,6 +266,33 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   t->W = t->WL * t->RPL;
   const int W = t->W;
   t->n_pad = ((t->ndof + W - 1) / W) * W;
+  // ---- solver geometry (see TopoDev) ----
+  const int n = t->ndof;
+  const int nteams = (t->G / t->WL == 2 && t->RPL == 1 && !tb_env_int("TRUSS_ONE_SIDED", 0)) ? 2 : 1;
+  int KA, mid, rowsA, rowsB, zlen, dlen, zslot;
+  if (nteams == 2) {
+    KA = n > W ? (n - W + 1) / 2 : 0;
+    mid = n - 2 * KA;
+    rowsA = KA + 2 * W;
+    rowsB = KA + W;
+    zlen = KA + 2 * W;
+    dlen = KA + W;
+    zslot = n + 2 * W;
+  } else {
+    KA = t->n_pad;
+    mid = 0;
+    rowsA = t->n_pad + W;
+    rowsB = 0;
+    zlen = t->n_pad + W;
+    dlen = t->n_pad;
+    zslot = t->n_pad;
+  }
+  // band offset (in doubles) of the lower-band entry (r, c), r >= c, original solver positions
+  auto band_off = [&](int r, int c) -> int {
+    if (nteams == 1 || r < n - KA) return r * W + (r - c);              // team A: its part + middle rows
+    int rb = n - 1 - r, cb = n - 1 - c;                                    // team B frame: cb >= rb
+    return (rowsA + cb) * W + (cb - rb);
+  };
 
   // solver position -> reference DOF (0-based) and node*2+comp
   t->perm.assign(t->ndof, -1);
@@ -280,20 +307,21 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     }
   }
   // assembly codes (FEM_2Dtruss.py:320-324 restricted to the lower band)
-  std::vector<int32_t> asm_code(10 * (size_t)E, -1);
+  std::vector<int16_t> asm_code(10 * (size_t)E, -1);
   bool band_ok = true;
   for (int e = 0; e < E; ++e) {
     int a = conn[2 * e], b = conn[2 * e + 1];
     int pa[2] = {dofpos[2 * a], dofpos[2 * a + 1]}, pb[2] = {dofpos[2 * b], dofpos[2 * b + 1]};
-    int n = 0;
+    int cnt = 0;
     auto add = [&](int r, int c, int type, int neg) {
-      int32_t code = -1;
+      int code = -1;
       if (r >= 0 && c >= 0) {
         if (r < c) std::swap(r, c);
         if (r - c >= W) band_ok = false;
-        code = ((r * W + (r - c)) << 3) | (type << 1) | neg;
+        code = (band_off(r, c) << 3) | (type << 1) | neg;
+        if (code > 32767) band_ok = false;
       }
-      asm_code[10 * (size_t)e + n++] = code;
+      asm_code[10 * (size_t)e + cnt++] = (int16_t)code;
     };
     add(pa[0], pa[0], 0, 0);
     add(pa[1], pa[1], 2, 0);
@@ -308,7 +336,15 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   }
   if (!band_ok) {
     delete t;
-    return tb_fail(TRUSS_EUNSUPPORTED, "internal: band wider than window");
+    return tb_fail(TRUSS_EUNSUPPORTED, "internal: band wider than window / offsets beyond int16");
+  }
+  // band offsets of the node-diagonal 2x2 block entries (x,x), (y,y), (x,y)
+  std::vector<int16_t> diagoff(3 * (size_t)N, -1);
+  for (int nd = 0; nd < N; ++nd) {
+    int px = dofpos[2 * nd], py = dofpos[2 * nd + 1];
+    if (px >= 0) diagoff[3 * nd + 0] = (int16_t)band_off(px, px);
+    if (py >= 0) diagoff[3 * nd + 1] = (int16_t)band_off(py, py);
+    if (px >= 0 && py >= 0) diagoff[3 * nd + 2] = (int16_t)band_off(std::max(px, py), std::min(px, py));
   }
   std::vector<int16_t> conn16(2 * (size_t)E);
   for (int i = 0; i < 2 * E; ++i) conn16[i] = (int16_t)conn[i];
@@ -356,7 +392,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
       }
   }
   size_t o_ar = tb_push(blob, area), o_isr = tb_push(blob, isr);
-  size_t o_ad = tb_push(blob, adj8);
+  size_t o_ad = tb_push(blob, adj8), o_do = tb_push(blob, diagoff);
   blob.resize((blob.size() + 15) & ~size_t(15));
   t->blob = tb_dev_alloc(blob.size());
   if (!t->blob || !tb_dev_upload(t->blob, blob.data(), blob.size())) {
@@ -389,6 +425,15 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.f_area = (int32_t)o_ar;
   D.f_isr = (int32_t)o_isr;
   D.f_adj8 = (int32_t)o_ad;
+  D.f_diagoff = (int32_t)o_do;
+  D.nteams = nteams;
+  D.KA = KA;
+  D.mid = mid;
+  D.rowsA = rowsA;
+  D.rowsB = rowsB;
+  D.zlen = zlen;
+  D.dlen = dlen;
+  D.zslot = zslot;
   D.e_mod = e_mod;
   D.long_stress = long_stress;
   // LDS layout: [copy of the blob][env 0][env 1]...; every array 16-byte aligned
@@ -400,7 +445,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   };
   // band region; after the back substitution it is reused as the output staging area
   {
-    size_t band = sizeof(double) * (size_t)(t->n_pad + W) * W;
+    size_t band = sizeof(double) * (size_t)(rowsA + rowsB) * W;
     size_t so = 0;
     auto sub = [&](size_t bytes) {
       size_t o = so;
@@ -413,17 +458,21 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     D.so_mu = sub(sizeof(float) * N);
     D.so_md = sub(sizeof(float) * N);
     D.so_comp = sub((size_t)E);
+    D.o_red = -1;  // set below: objective partials live behind the staging rows (the band is dead by then)
+    size_t red_off = so;
+    so += sizeof(double) * TRUSS_NRED * (size_t)t->G;
     D.o_kb = carve(std::max(band, so));
+    D.o_red = D.o_kb + (int32_t)red_off;
   }
-  // solver scratch; before the solver the same bytes hold the per-element (k cc, k cs, k ss)
+  // solver scratch; before the solver the same bytes hold the per-element (k cc, k cs, k ss), after
+  // the back substitution `red` (objective partials) reuses the z vectors
   {
     size_t o0 = off;
-    D.o_zs = carve(sizeof(double) * (t->n_pad + W));
-    D.o_dinv = carve(sizeof(double) * t->n_pad);
-    D.o_xsol = carve(sizeof(double) * (t->n_pad + 1));
-    D.o_red = carve(sizeof(double) * TRUSS_NRED * t->G);
+    D.o_zs = carve(sizeof(double) * (size_t)zlen * nteams);
+    D.o_dinv = carve(sizeof(double) * (size_t)dlen * nteams);
+    D.o_xsol = carve(sizeof(double) * (zslot + 1));
     D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
-    D.o_zring = carve(sizeof(double) * 2 * W);
+    D.o_zring = carve(sizeof(double) * 2 * W * nteams);
     D.o_ev = (int32_t)o0;
     size_t need = sizeof(double) * 3 * ((size_t)E + 1);
     if (off - o0 < need) off = (o0 + need + 15) & ~size_t(15);
@@ -432,8 +481,14 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.o_y = carve(sizeof(float) * N);
   D.o_x = carve(sizeof(float) * N);
   D.o_tg = carve(sizeof(float) * N);
-  D.o_geo = carve(sizeof(float) * 2 * N);
-  D.o_tac = carve(sizeof(float) * 3 * N);
+  {
+    size_t o0 = off;
+    D.o_geo = carve(sizeof(float) * 2 * N);
+    D.o_tac = carve(sizeof(float) * 3 * N);
+    D.o_mrg = (int32_t)o0;  // merge scratch of the two-sided solver: the actions are dead by then
+    size_t need = nteams == 2 ? sizeof(double) * (size_t)(W * W + W) : 0;
+    if (off - o0 < need) off = (o0 + need + 15) & ~size_t(15);
+  }
   D.o_sec = carve(sizeof(int32_t) * E);
   // stagger env regions across LDS banks: stride = 64 B (mod 256 B)
   size_t stride = (off + 255) & ~size_t(255);

@@ -142,3 +142,20 @@ def test_product_refuses_non_hip_default(monkeypatch, tmp_path):
     missing = tmp_path / "nope.so"
     with pytest.raises(tm.TrussError):
         tm._lib.TrussLib(str(missing))
+
+
+def test_hip_kernels_use_no_scratch():
+    """A runtime-indexed register array silently moves the whole lane state to scratch memory
+    (hidden HBM traffic + latency; it happened twice during development).  The resource report of
+    the shipped build must show zero scratch and zero VGPR spills for every product kernel."""
+    rep = os.path.join(os.path.dirname(tm._lib.DEFAULT_LIB), "libtruss_mi355.resources.txt")
+    assert os.path.exists(rep), "build with `make -C mop-truss-marl_amd/csrc` (or __graft_entry__.build())"
+    assert os.path.getmtime(rep) >= os.path.getmtime(tm._lib.DEFAULT_LIB) - 120
+    txt = open(rep).read()
+    names = re.findall(r"Function Name: (\S+)", txt)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
+    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", txt)]
+    assert len(names) == len(scratch) == len(spills) and len(names) >= 9
+    assert sum("truss_step_kernel" in n for n in names) >= 8 and any("truss_obs_kernel" in n for n in names)
+    assert all(v == 0 for v in scratch), dict(zip(names, scratch))
+    assert all(v == 0 for v in spills), dict(zip(names, spills))
