@@ -1,0 +1,353 @@
+"""Drop-in replacement for the reference's truss2D_RL.py (MADDPG with GCN actors/critics), restated in
+PyTorch-ROCm (the reference is TensorFlow 2.11 / Keras / Spektral 1.2; neither is available here, so
+parity is STRUCTURAL: same layers, shapes, data flow, update rules and quirks -- not bit-level).
+
+    OUNoise                         truss2D_RL.py:41-48
+    multimodes_actor                :49-127   13 GCNConv (Spektral GCNConv = A @ (X W) + b, no activation)
+    multimodes_critic               :130-266  21 GCNConv + Dense(c_nn) x2 + Dense(1)
+    multimodals_OneAgent            :269-404
+    MADDPG                          :407-704  .agents[i].act(...), .remember(...), .train(), .update()
+
+Quirks of the reference that are kept on purpose:
+  * the Pareto-graph embedding is tiled over the nodes with stack(axis=-1) followed by a RESHAPE
+    (not a transpose) to [batch, N, hidden] (:87-93);
+  * `done` is unpacked from sample slot 4 (an action array) and compared with `is 1`, so the terminal
+    branch of the TD target never fires (:605-611); the target averages the three next-state Qs;
+  * the actor is stepped by a FRESH Adam(lr*0.1, clipnorm=1) every call (:629);
+  * `OneAgent.update()` acts only when update_num == 1000, `MADDPG.update()` calls it only when
+    agents[0].update_num % 300 == 0 -> the targets keep their initial hard copy (:392-400, :692-699).
+
+Multi-GPU: pass `dist=torch.distributed` (backend "nccl" = RCCL on MI355X): every optimiser step is
+preceded by ONE all-reduce of the flat gradient buffer; the env batch itself needs
+no collective.
+"""
+import random
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from set_seed_global import seedThis
+
+random.seed(seedThis)
+np.random.seed(seedThis)
+torch.manual_seed(seedThis)
+
+
+class OUNoise():
+    def __init__(self, mu, theta, sigma):
+        self.mu, self.theta, self.sigma = mu, theta, sigma
+        self.dt = 0.0001
+
+    def gen_noise(self, x):
+        return self.theta * (self.mu - x) * self.dt + self.sigma * np.random.randn(1)
+
+
+class GCNConv(nn.Module):
+    """Spektral 1.2 GCNConv in batch mode with a dense, already normalised adjacency:
+    out = A @ (X @ W) + b; kernel GlorotNormal, bias zeros, no activation."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.lin = nn.LazyLinear(channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self._init = False
+
+    def forward(self, x, a):
+        h = self.lin(x)
+        if not self._init:
+            nn.init.xavier_normal_(self.lin.weight)
+            self._init = True
+            h = self.lin(x)
+        return torch.matmul(a, h) + self.bias
+
+
+def _tile_pool(x_pool, n_nodes):
+    """[B,H] -> stack N copies on the last axis -> reshape (not transpose) to [B,N,H] (:87-93)."""
+    B, H = x_pool.shape
+    return x_pool.unsqueeze(-1).expand(B, H, n_nodes).reshape(B, n_nodes, H)
+
+
+class multimodes_actor(nn.Module):
+    def __init__(self, n_hidden, n_action1, n_action2):
+        super().__init__()
+        g = lambda c: GCNConv(c)
+        self.gcn_l1_1, self.gcn_l1_2, self.gcn_l1_3, self.gcn_l1_4 = g(n_hidden), g(n_hidden), g(n_hidden), g(n_hidden)
+        self.gcn_l2_1, self.gcn_l2_2, self.gcn_l2_3 = g(n_hidden), g(n_hidden), g(n_hidden)
+        self.gcn_l2_4, self.gcn_l2_5 = g(n_hidden), g(n_hidden)
+        self.gcn_l3_1, self.gcn_l3_2 = g(n_hidden), g(n_hidden)
+        self.gcn_l4_1, self.gcn_l4_2 = g(n_action1), g(n_action2)
+
+    def forward(self, inputs):
+        x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p = inputs
+        relu = torch.relu
+        x_1_1 = relu(self.gcn_l1_1(x_n, A_n))
+        x_1_2 = relu(self.gcn_l1_2(x_n, A_n))
+        x_1_3 = relu(self.gcn_l1_3(x_n, A_n))
+        x_1_4 = relu(self.gcn_l1_4(x_p, A_p)).sum(dim=1)          # GlobalSumPool
+        x_1_4 = _tile_pool(x_1_4, x_1_1.shape[1])
+        x_2_1 = relu(self.gcn_l2_1(x_1_1, A_n))
+        x_2_2 = relu(self.gcn_l2_2(x_1_2, A_n_ts))
+        x_2_3 = relu(self.gcn_l2_3(x_1_2, A_n_cs))
+        x_2_4 = relu(self.gcn_l2_4(x_1_3, A_s))
+        x_2_5 = relu(self.gcn_l2_5(x_1_4, A_n))
+        x_3 = x_2_1 + x_2_2 + x_2_3 + x_2_4 + x_2_5
+        x_3_1 = relu(self.gcn_l3_1(x_3, A_n))
+        x_3_2 = relu(self.gcn_l3_2(x_3, A_s))
+        out_1 = torch.sigmoid(self.gcn_l4_1(x_3_1, A_n))
+        out_2 = torch.sigmoid(self.gcn_l4_2(x_3_2, A_n))
+        return out_1, out_2
+
+
+class multimodes_critic(nn.Module):
+    def __init__(self, n_hidden, n_q):
+        super().__init__()
+        self.l1 = nn.ModuleList([GCNConv(n_hidden) for _ in range(10)])
+        self.l2 = nn.ModuleList([GCNConv(n_hidden) for _ in range(11)])
+        self.dense_1 = nn.LazyLinear(n_q)
+        self.dense_2 = nn.Linear(n_q, n_q)
+        self.dense_out = nn.Linear(n_q, 1)
+        nn.init.xavier_normal_(self.dense_2.weight)
+
+    def forward(self, inputs):
+        x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p, self_g, self_t, other_g1, other_t1, other_g2, other_t2 = inputs
+        relu = torch.relu
+        x_1_1 = relu(self.l1[0](x_n, A_n))
+        x_1_2 = relu(self.l1[1](x_n, A_n))
+        x_1_3 = relu(self.l1[2](x_n, A_n))
+        x_1_4 = _tile_pool(relu(self.l1[3](x_p, A_p)).sum(dim=1), x_1_1.shape[1])
+        acts = [self_g, self_t, other_g1, other_t1, other_g2, other_t2]
+        x_1_a = [relu(self.l1[4 + i](a, A_n)) for i, a in enumerate(acts)]
+        x2 = [relu(self.l2[0](x_1_1, A_n)), relu(self.l2[1](x_1_2, A_n_ts)), relu(self.l2[2](x_1_2, A_n_cs)),
+              relu(self.l2[3](x_1_3, A_s))]
+        x2 += [relu(self.l2[4 + i](h, A_n)) for i, h in enumerate(x_1_a)]
+        x2.append(relu(self.l2[10](x_1_4, A_n)))
+        q = torch.cat([h.sum(dim=1) for h in x2], dim=-1)            # 11 x GlobalSumPool -> Concatenate
+        q = relu(self.dense_1(q))
+        q = relu(self.dense_2(q))
+        return self.dense_out(q)
+
+
+def _clip_each(params, max_norm=1.0):
+    """Keras `clipnorm`: every gradient tensor is clipped to L2 norm <= clipnorm on its own."""
+    for p in params:
+        if p.grad is not None:
+            n = p.grad.norm()
+            if n > max_norm:
+                p.grad.mul_(max_norm / (n + 1e-12))
+
+
+def _allreduce_grads(params, dist):
+    """One fused all-reduce of the flat gradient buffer (mean over ranks)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+class multimodals_OneAgent:
+    def __init__(self, lr, ep, epd, gamma, a_nn, c_nn, num_action1, num_action2, mu_s, theta_s, sigma_s, mu_t, theta_t,
+                 sigma_t, all_agent, batch, device="cpu"):
+        self.number = 1
+        self.lr, self.epmin, self.gamma = lr, 0.05, gamma
+        self.a_nn, self.c_nn = a_nn, c_nn
+        self.num_action1, self.num_action2 = num_action1, num_action2
+        self.tau = 0.005
+        self.noise_geo = [OUNoise(mu_s[i], theta_s[i], sigma_s[i]) for i in range(num_action1)]
+        self.noise_topo = [OUNoise(mu_t[i], theta_t[i], sigma_t[i]) for i in range(num_action2)]
+        self.update_num = 0
+        self.update_lr = 0
+        self.c_loss = []
+        self.device = torch.device(device)
+        self.actor_model = multimodes_actor(a_nn, num_action1, num_action2).to(self.device)
+        self.target_actor_model = multimodes_actor(a_nn, num_action1, num_action2).to(self.device)
+        self.critic_model = multimodes_critic(a_nn, c_nn).to(self.device)
+        self.target_critic_model = multimodes_critic(a_nn, c_nn).to(self.device)
+        self.critic_opt = None       # created once the lazy layers are materialised
+        self.all_agent = all_agent
+        self.batch_size = batch
+        self._targets_ready = False
+
+    def _t(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device)
+
+    def act(self, x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p):
+        ins = [self._t(v).unsqueeze(0) for v in (x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p)]
+        with torch.no_grad():
+            out_geo, out_topo = self.actor_model(ins)
+        action_geo = out_geo[0].cpu().numpy().astype(np.float32)
+        for i in range(len(action_geo)):
+            for j in range(len(action_geo[i])):
+                action_geo[i][j] += self.noise_geo[j].gen_noise(action_geo[i][j])[0]
+        action_topo = out_topo[0].cpu().numpy().astype(np.float32)
+        for i in range(len(action_topo)):
+            for j in range(len(action_topo[i])):
+                action_topo[i][j] += self.noise_topo[j].gen_noise(action_topo[i][j])[0]
+        self.update_num += 1
+        return action_geo, action_topo
+
+    @staticmethod
+    def _copy(src, dst, tau=None):
+        with torch.no_grad():
+            for ps, pd in zip(src.parameters(), dst.parameters()):
+                if isinstance(ps, nn.parameter.UninitializedParameter) or isinstance(pd, nn.parameter.UninitializedParameter):
+                    return False
+                pd.copy_(ps if tau is None else ps * tau + pd * (1 - tau))
+        return True
+
+    def _update_actor_target(self, init=None):
+        return self._copy(self.actor_model, self.target_actor_model, None if init == 1 else self.tau)
+
+    def _update_critic_target(self, init=None):
+        return self._copy(self.critic_model, self.target_critic_model, None if init == 1 else self.tau)
+
+    def update(self):
+        if self.update_num == 1000:
+            self._update_actor_target()
+            self._update_critic_target()
+            self.update_num = 0
+            print('update target')
+
+    def update_init(self):
+        a = self._update_actor_target(1)
+        c = self._update_critic_target(1)
+        self._targets_ready = bool(a and c)
+
+
+class MADDPG:
+    def __init__(self, lr, ep, epd, gamma, a_nn, c_nn, max_mem, num_agents, num_action, mu, theta, sigma,
+                 max_poss_n_num=1, device="cpu", dist=None):
+        self.num_agents = num_agents
+        self.lr, self.epint, self.ep, self.epd, self.epmin, self.gamma = lr, ep, ep, epd, 0.05, gamma
+        self.a_nn, self.c_nn = a_nn, c_nn
+        self.mu, self.theta, self.sigma = mu, theta, sigma
+        self.temprp = deque(maxlen=max_mem)
+        for _ in range(max_poss_n_num):
+            self.temprp.append(deque(maxlen=max_mem))
+        self.agents, self.update_counter = [], []
+        self.num_state = [0, 0]
+        self.num_action = num_action
+        self.batch_size = 32
+        self.max_poss_n_num = max_poss_n_num
+        self.device = torch.device(device)
+        self.dist = dist
+        self.gen_agents()
+
+    def gen_agents(self):
+        for i in range(3):       # the reference builds exactly three agents (:438-452)
+            ag = multimodals_OneAgent(self.lr, self.ep, self.epd, self.gamma, self.a_nn, self.c_nn, self.num_action[0],
+                                      self.num_action[1], self.mu[0], self.theta[0], self.sigma[0], self.mu[1],
+                                      self.theta[1], self.sigma[1], self.num_agents, self.batch_size, device=self.device)
+            ag.number = i + 1
+            self.agents.append(ag)
+            self.update_counter.append(0)
+
+    def remember(self, state, a0_g, a0_t, a1_g, a1_t, a2_g, a2_t, reward, next_state1, next_state2, next_state3, done, n_node):
+        self.temprp[0].append([state, a0_g, a0_t, a1_g, a1_t, a2_g, a2_t, reward, next_state1, next_state2, next_state3, done])
+
+    def _stack(self, states, idx):
+        return torch.as_tensor(np.array([s[idx] for s in states]), dtype=torch.float32, device=self.device)
+
+    def _state_tensors(self, states):
+        return [self._stack(states, i) for i in range(8)]      # x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p
+
+    @staticmethod
+    def _actor_in(s):
+        return [s[0], s[1], s[2], s[3], s[4], s[6], s[7]]
+
+    def _ensure_ready(self, S, acts):
+        """materialise lazy layers, take the initial hard copy of the targets (update_init, :402-404)"""
+        for i, ag in enumerate(self.agents):
+            if not ag._targets_ready:
+                with torch.no_grad():
+                    ag.actor_model(self._actor_in(S))
+                    ag.target_actor_model(self._actor_in(S))
+                    ag.critic_model(S + acts)
+                    ag.target_critic_model(S + acts)
+                ag.update_init()
+            if ag.critic_opt is None:
+                ag.critic_opt = torch.optim.Adam(ag.critic_model.parameters(), lr=ag.lr, eps=1e-7)
+
+    def train(self):
+        batch_size = self.batch_size
+        if len(self.temprp[0]) < batch_size:
+            return
+        samples = random.sample(self.temprp[0], batch_size)
+        t = lambda k: torch.as_tensor(np.array([v[k] for v in samples]), dtype=torch.float32, device=self.device)
+        S = self._state_tensors([v[0] for v in samples])
+        NS = [self._state_tensors([v[8 + f] for v in samples]) for f in range(3)]
+        A = [(t(1), t(2)), (t(3), t(4)), (t(5), t(6))]
+        R = torch.as_tensor(np.array([v[7] for v in samples]), dtype=torch.float32, device=self.device)   # [B,3]
+        flat = lambda order: [A[order[0]][0], A[order[0]][1], A[order[1]][0], A[order[1]][1], A[order[2]][0], A[order[2]][1]]
+        orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]          # (self, other1, other2) per agent (:561-563)
+        self._ensure_ready(S, flat(orders[0]))
+        with torch.no_grad():
+            q_next = []
+            for f in range(3):
+                na = [ag.target_actor_model(self._actor_in(NS[f])) for ag in self.agents]
+                qf = []
+                for i, ag in enumerate(self.agents):
+                    o = orders[i]
+                    qf.append(ag.target_critic_model(NS[f] + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1],
+                                                              na[o[2]][0], na[o[2]][1]]))
+                q_next.append(qf)
+        for i, ag in enumerate(self.agents):
+            o = orders[i]
+            # TD target; `done` never fires in the reference (it compares an action array with `is 1`)
+            y = R[:, i:i + 1] + self.gamma * (q_next[0][i] + q_next[1][i] + q_next[2][i]) / 3
+            ag.critic_opt.zero_grad(set_to_none=True)
+            loss = torch.mean((ag.critic_model(S + flat(o)) - y) ** 2)
+            loss.backward()
+            cp = list(ag.critic_model.parameters())
+            _allreduce_grads(cp, self.dist)
+            _clip_each(cp)
+            ag.critic_opt.step()
+            ag.c_loss.append(float(loss.detach()))
+            # actor: maximise the own critic with all three actors re-evaluated (:617-629)
+            preds = [a2.actor_model(self._actor_in(S)) for a2 in self.agents]
+            q = ag.critic_model(S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
+                                     preds[o[2]][1]])
+            actor_loss = -q.mean()
+            ap = list(ag.actor_model.parameters())
+            for p in ap:
+                p.grad = None
+            grads = torch.autograd.grad(actor_loss, ap, allow_unused=True)
+            for p, g in zip(ap, grads):
+                p.grad = g
+            _allreduce_grads(ap, self.dist)
+            _clip_each(ap)
+            torch.optim.Adam(ap, lr=ag.lr * 0.1, eps=1e-7).step()       # a fresh optimiser every call
+
+    def update(self):
+        interval = len(self.agents) * 100
+        if self.agents[0].update_num % interval == 0:
+            for i in range(len(self.agents)):
+                self.agents[i].update()
+                print('update target agent{}'.format(i + 1))
+
+    def update_init(self):
+        for ag in self.agents:
+            ag.update_init()
+
+    # checkpoints (master_DDPG_truss2D_MO.py:710-733, 885-906 use Keras save/load_weights)
+    def save_weights(self, prefix):
+        for i, ag in enumerate(self.agents):
+            torch.save({"actor": ag.actor_model.state_dict(), "critic": ag.critic_model.state_dict()},
+                       "{}Agent{}_pickle.pt".format(prefix, i + 1))
+
+    def load_weights(self, prefix):
+        for i, ag in enumerate(self.agents):
+            sd = torch.load("{}Agent{}_pickle.pt".format(prefix, i + 1), weights_only=True, map_location=self.device)
+            ag.actor_model.load_state_dict(sd["actor"])
+            ag.target_actor_model.load_state_dict(sd["actor"])
+            ag.critic_model.load_state_dict(sd["critic"])
+            ag.target_critic_model.load_state_dict(sd["critic"])
+            ag._targets_ready = True

@@ -371,6 +371,63 @@ def _reward(outdir, codedir_test):
         sc_scal.append([len(front), max_d, dis_d, p_cd, sum_d, float(std_cd)])
     out["cull_in"] = np.array(sc_in); out["cull_front"] = np.array(sc_front)
     out["cull_scalars"] = np.array(sc_scal, dtype=np.float64)
+    # G5: the difference-reward block of run() (master_DDPG_truss2D_MO.py:263-368) evaluated with the
+    # reference's own simple_cull / union_rectangles_fastest.  The master cannot be imported
+    # (tensorflow), so its formulas are restated here next to the line they come from.
+    rb_in, rb_out = [], []
+    for t in range(120):
+        nf = int(rng.integers(1, 7))
+        front_no = (rng.random((nf, 2)) * 0.9 + 0.05)
+        front_no = [[float(a), float(b), 0.0, 0.0] for a, b in front_no]
+        Pf_HV = [list(r) for r in front_no] if t % 3 else [[1, 1, 0, 0]]
+        n_pf = len(Pf_HV)
+        parent = Pf_HV[int(rng.integers(0, n_pf))][:2]
+        pts = rng.random((3, 4))
+        pts[:, 2:] *= 1.3                       # some infeasible agents
+        if t % 5 == 0:
+            pts[:, :2] *= 1.2                   # objectives above 1
+        points = [[np.float32(v) for v in row] for row in pts]
+        ref_points = [float(min(1, 0.2 * (1 + t % 5))), float(min(1, 0.2 * (1 + (t // 5) % 5)))]
+        feas = [(p[0] <= 1 and p[1] <= 1 and p[2] <= 1 and p[3] <= 1) for p in points]
+        random.seed(11)
+        ff = []
+        for i in range(3):                      # :267-287 leave-one-out fronts
+            f_i = [e for e in front_no]
+            for j in range(3):
+                if j != i and feas[j]:
+                    f_i.append(points[j])
+            ff.append(U.simple_cull(f_i))
+        f_all = [e for e in front_no]           # :291-305
+        for j in range(3):
+            if feas[j]:
+                f_all.append(points[j])
+        front, max_d, dis_d, p_cd, sum_distance, std_cd = U.simple_cull(f_all)
+        hv_i = [U.union_rectangles_fastest(ff[i][0], OPEN, CLOSE, ref_point=ref_points) for i in range(3)]   # :311-313
+        hyperV = U.union_rectangles_fastest(front, OPEN, CLOSE, ref_point=ref_points)                        # :314
+        compareV = U.union_rectangles_fastest(Pf_HV, OPEN, CLOSE, ref_point=ref_points)                      # :316
+        Real_compareV = U.union_rectangles_fastest(Pf_HV, OPEN, CLOSE, ref_point=[1, 1])                     # :317
+        hv_i = [max([0, h - compareV]) for h in hv_i]                                                        # :324-332
+        hyperV = max([0, hyperV - compareV])                                                                 # :336
+        w = [0, 0, 0]
+        if feas[0]:
+            w[0] = (1) * max([0, (parent[0] - points[0][0])]) + (0) * max([0, (parent[1] - points[0][0])])   # :348
+        if feas[1]:
+            w[1] = (1 / 2) * max([0, (parent[0] - points[1][0])]) + (1 / 2) * max([0, (parent[1] - points[1][0])])  # :350
+        if feas[2]:
+            w[2] = (0) * max([0, (parent[0] - points[2][0])]) + (1) * max([0, (parent[1] - points[2][0])])   # :352
+        R = []
+        for i in range(3):                                                                                   # :365-367
+            R.append(0.25 * w[i] / (max([0.25, Real_compareV]) * n_pf) + 0.25 * (hyperV - hv_i[i]) / (max([0.25, Real_compareV]) * n_pf)
+                     + 10 * (Real_compareV / n_pf) - 0.05 * max([0, min([1, std_cd])]) / n_pf
+                     + 0.05 * sum_distance / (2 * (max([0.25, Real_compareV]) ** 0.5) * n_pf))
+        G_U = (20 * Real_compareV / n_pf) - (1 * std_cd) / n_pf + 1 * sum_distance / n_pf                    # :368
+        pad = np.full((6, 4), np.nan); pad[:nf] = np.array(front_no)
+        padh = np.full((6, 4), np.nan); padh[:n_pf] = np.array(Pf_HV, dtype=np.float64)
+        rb_in.append(np.concatenate([pad.ravel(), padh.ravel(), np.array(parent, dtype=np.float64),
+                                     np.array(points, dtype=np.float64).ravel(), np.array(ref_points)]))
+        rb_out.append([float(R[0]), float(R[1]), float(R[2]), float(G_U)])
+    out["rb_in"] = np.array(rb_in)
+    out["rb_out"] = np.array(rb_out, dtype=np.float64)
     np.savez_compressed(os.path.join(outdir, "reward.npz"), **out)
     print("wrote reward", file=sys.stderr)
 

@@ -1,0 +1,156 @@
+"""master_DDPG_truss2D_MO (reward block, Pareto-graph padding, the run() loop) and the PyTorch MADDPG
+(truss2D_RL) -- CPU tests; run() goes through the lane emulator."""
+import contextlib
+import io
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+import parity_common as pc
+
+
+def test_difference_reward_matches_reference_formulas():
+    import master_DDPG_truss2D_MO as M
+    f = np.load(os.path.join(GOLDEN, "reward.npz"))
+    for row, want in zip(f["rb_in"], f["rb_out"]):
+        fn = row[:24].reshape(6, 4)
+        front_no = fn[~np.isnan(fn[:, 0])].tolist()
+        ph = row[24:48].reshape(6, 4)
+        Pf_HV = ph[~np.isnan(ph[:, 0])].tolist()
+        parent = row[48:50].tolist()
+        points = [[np.float32(v) for v in p] for p in row[50:62].reshape(3, 4)]
+        ref_points = row[62:64].tolist()
+        random.seed(11)
+        R0, R1, R2, GU, _, _ = M.difference_reward(front_no, Pf_HV, parent, points, ref_points, len(Pf_HV))
+        np.testing.assert_allclose([R0, R1, R2, GU], want, rtol=1e-12, atol=1e-12)
+
+
+def test_pad_pareto_graph():
+    import master_DDPG_truss2D_MO as M
+    from truss2D_ENV import pareto_state_data
+    pf = [[0.2, 0.8], [0.5, 0.5], [0.9, 0.1]]
+    x, A = pareto_state_data(pf, index=1)
+    assert x.shape == (3, 4) and x[1, 2] == 1 and abs(x[0, 3] - 3 / 20) < 1e-7
+    np.testing.assert_allclose(A, A.T)
+    xp, Ap = M.pad_pareto_graph(x, A)
+    assert xp.shape == (20, 4) and Ap.shape == (20, 20)
+    assert np.array_equal(xp[:3], x) and not xp[3:].any() and not Ap[3:].any() and not Ap[:, 3:].any()
+    xb, Ab = M.pad_pareto_graph(np.ones((25, 4)), np.ones((25, 25)))
+    assert xb.shape == (20, 4) and Ab.shape == (20, 20)
+
+
+def _tiny_maddpg(M, device="cpu", dist=None):
+    import truss2D_RL as RL
+    return RL.MADDPG(1e-4, 1, 0.95, 0.99, 8, 8, 1000, 3, [2, 3], M.mu, M.theta, M.sigma, device=device, dist=dist)
+
+
+def test_actor_critic_shapes_and_quirks():
+    import truss2D_RL as RL
+    torch.manual_seed(0)
+    B, N, P = 4, 12, 20
+    actor = RL.multimodes_actor(16, 2, 3)
+    ins = [torch.rand(B, N, 13), torch.rand(B, N, N), torch.rand(B, N, N), torch.rand(B, N, N), torch.rand(B, N, N),
+           torch.rand(B, P, 4), torch.rand(B, P, P)]
+    g, t = actor(ins)
+    assert g.shape == (B, N, 2) and t.shape == (B, N, 3) and g.min() >= 0 and g.max() <= 1
+    critic = RL.multimodes_critic(16, 8)
+    cin = ins[:5] + [torch.rand(B, N, N)] + ins[5:] + [g, t, g, t, g, t]
+    assert critic(cin).shape == (B, 1)
+    assert sum(1 for m in actor.modules() if isinstance(m, RL.GCNConv)) == 13
+    assert sum(1 for m in critic.modules() if isinstance(m, RL.GCNConv)) == 21
+    # the Pareto embedding is tiled with stack(axis=-1) + RESHAPE (not transpose), truss2D_RL.py:87-93
+    x = torch.arange(6.0).reshape(2, 3)
+    tiled = RL._tile_pool(x, 4)
+    assert tiled.shape == (2, 4, 3)
+    assert torch.equal(tiled[0].reshape(-1), x[0].unsqueeze(-1).expand(3, 4).reshape(-1))
+    # GCNConv = A @ (X W) + b
+    conv = RL.GCNConv(5)
+    X, A = torch.rand(2, 7, 3), torch.rand(2, 7, 7)
+    out = conv(X, A)
+    np.testing.assert_allclose(out.detach().numpy(), (A @ (X @ conv.lin.weight.T) + conv.bias).detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_run_two_game_steps_emulated(tmp_path, monkeypatch):
+    """One short game through run(): three agents act on every archived design, rewards are finite,
+    the archive is a non-dominated feasible set, transitions reach the replay buffer and train() runs."""
+    import FEM_2Dtruss
+    import truss2D_ENV
+    import truss2D_GEN
+    import master_DDPG_truss2D_MO as M
+    monkeypatch.chdir(tmp_path)
+    FEM_2Dtruss._LIB = pc.emu_lib()
+    try:
+        random.seed(3); np.random.seed(3); torch.manual_seed(3)
+        M.reinforcement_learning = _tiny_maddpg(M)
+        M.reinforcement_learning.batch_size = 2
+        with contextlib.redirect_stdout(io.StringIO()) as log:
+            c = M.trainChoice[0]
+            gm = truss2D_GEN.gen_model(6, 2, c[0], c[1], c[2], 0.2, 0, -100000, 'roof', None, 1)
+            game = truss2D_ENV.Game_research04(3, gm, 2)
+            M.env1_test = truss2D_ENV.ENV(game)
+            M.game_reward = [0, 0, 0, 0]
+            M.hyperS, M.Utility, M.numHV = [], [], []
+            n_fem = M.run(game, train_period=1, savedata=1)
+        assert n_fem >= 9 and n_fem % 3 == 0
+        assert M.env1_test.over == 1 and game.game_step == 4
+        assert len(M.hyperS) == 3 and all(np.isfinite(M.hyperS)) and all(0 <= h <= 1 for h in M.hyperS)
+        assert all(np.isfinite(M.game_reward))
+        assert len(M.reinforcement_learning.temprp[0]) >= 1
+        assert "Step 3 ||" in log.getvalue()
+        d = tmp_path / "MADDPG_Model_data_txt_Game1"
+        assert (d / "out.txt").exists() and any(p.name.startswith("Game1_Step") for p in d.iterdir())
+        txt = (d / "Game1_Step1_Sol_0.txt").read_bytes()
+        assert txt.startswith(b" 1, [0, -100000]\r\n")            # Load repr, then nodes, then elements (GEN:193-211)
+        assert len(M.reinforcement_learning.agents[0].c_loss) >= 1   # train() ran
+    finally:
+        FEM_2Dtruss._LIB = None
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import master_DDPG_truss2D_MO as M
+    torch.manual_seed(0); random.seed(100 + rank); np.random.seed(100 + rank)
+    rl = _tiny_maddpg(M, dist=dist)
+    rl.batch_size = 4
+    N, P = 12, 20
+    rng = np.random.default_rng(rank)          # different experience on every rank
+    mk = lambda: [rng.random((N, 13), dtype=np.float32)] + [rng.random((N, N), dtype=np.float32) for _ in range(5)] + \
+        [rng.random((P, 4), dtype=np.float32), rng.random((P, P), dtype=np.float32)]
+    for _ in range(6):
+        a = [rng.random((N, 2), dtype=np.float32), rng.random((N, 3), dtype=np.float32)] * 3
+        rl.remember(mk(), *a, [0.1, 0.2, 0.3], mk(), mk(), mk(), 0, 1)
+    rl.train()
+    rl.train()
+    w = torch.cat([p.detach().reshape(-1) for ag in rl.agents for p in list(ag.actor_model.parameters()) + list(ag.critic_model.parameters())])
+    gathered = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    if rank == 0:
+        out.put(float((gathered[0] - gathered[1]).abs().max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_keeps_ranks_in_sync():
+    """Data-parallel MADDPG over two gloo ranks: same initial weights, different replay samples, one fused
+    gradient all-reduce per optimiser step -> identical weights afterwards."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    diff = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert diff < 1e-6
