@@ -88,6 +88,7 @@ struct TopoDev {
   int32_t f_restslot;  // int16 [N][2]   reaction slot (reference order nsc-ndof-1) or -1
   int32_t f_asm;       // int16 [E][10]  (band offset << 3) | (type << 1) | negate, or -1
   int32_t f_diagoff;   // int16 [N][3]   band offsets of (x,x), (y,y), (x,y) of the node block, or -1
+  int32_t f_zcode;     // uint8 [nteams*zlen] load code of every z/P slot: bit0 comp (0 x, 1 y), bit1 loaded (bridge), bit2 loaded (roof)
   int32_t f_posnode;   // int16 [n_pad]  node*2+comp at solver position, -1 = padding row
   int32_t f_symn;      // int16 [n][2]   (dst, src)
   int32_t f_syme;      // int16 [n][2]
@@ -183,6 +184,7 @@ struct StepLane {
   TRUSS_HD const int16_t *t_restslot(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_restslot); }
   TRUSS_HD const int16_t *t_asm(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_asm); }
   TRUSS_HD const int16_t *t_diagoff(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_diagoff); }
+  TRUSS_HD const uint8_t *t_zcode(const TopoDev &T) const { return TB_TAB(uint8_t, TB, T.f_zcode); }
   TRUSS_HD const int16_t *t_posnode(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_posnode); }
   TRUSS_HD const int16_t *t_symn(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_symn); }
   TRUSS_HD const int16_t *t_syme(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_syme); }
@@ -569,12 +571,15 @@ struct StepLane {
   // ---- phase 5b: the element-value buffer is dead; its bytes become the solver scratch ----
   TRUSS_HD void solver_scratch_init(const TopoDev &T) {
     double *Z = zs(T);
-    for (int r = g; r < T.zlen * T.nteams; r += G) {
-      const int tm = r >= T.zlen, p = tm ? r - T.zlen : r;
-      Z[r] = team_load(T, tm, p);
+    const uint8_t *ZC = t_zcode(T);
+    const int lbit = is_roof ? 4 : 2;
+    for (int r = g; r < T.zlen * T.nteams; r += G) {   // load vector P in each team's frame (host table)
+      const int c = ZC[r];
+      Z[r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
     }
-    double *XS = xsol(T);
-    for (int r = g; r <= T.zslot; r += G) XS[r] = 0.0;  // also the zero slot the restrained DOFs read
+    tb_d2 *X2 = (tb_d2 *)__builtin_assume_aligned(xsol(T), 16);
+    const tb_d2 z2 = {0.0, 0.0};
+    for (int r = g; r < (T.zslot + 2) / 2; r += G) X2[r] = z2;  // incl. the zero slot restrained DOFs read
     double *RB = rbuf(T);
     for (int i = g; i < T.n_rest; i += G) RB[i] = 0.0;
   }
@@ -854,7 +859,7 @@ struct StepLane {
     RD[5 * G + g] = (double)bad;
   }
 
-  // copy one result row LDS -> HBM with the env's own G lanes (16-byte stores when possible)
+  // copy one result row LDS -> HBM with the env's own G lanes (generic fallback)
   TRUSS_HD void store_row(void *dst, const void *src, int nbytes) const {
     if ((nbytes & 15) == 0 && (((size_t)dst) & 15) == 0) {
       const tb_u4 *s4 = (const tb_u4 *)src;
@@ -870,53 +875,105 @@ struct StepLane {
       for (int q = g; q < nbytes; q += G) d1[q] = s1[q];
     }
   }
+  template <int IT>
+  TRUSS_HD void out_load(const void *src, int nq, tb_u4 (&v)[IT]) const {
+    const tb_u4 *s4 = (const tb_u4 *)src;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int q = g + G * i;
+      v[i] = s4[q < nq ? q : nq - 1];
+    }
+  }
+  template <int IT>
+  TRUSS_HD void out_store(void *dst, int nq, const tb_u4 (&v)[IT]) const {
+    tb_u4 *d4 = (tb_u4 *)dst;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int q = g + G * i;
+      d4[q < nq ? q : nq - 1] = v[i];  // clamped duplicates rewrite the same 16 bytes
+    }
+  }
 
-  // ---- phase 8a: stream the result rows out ----
+  // ---- phase 8a: stream the result rows out: every LDS read first, then every global store ----
   TRUSS_HD void phase_store(const TopoDev &T, const StepArgsDev &A) {
     if (!active) return;
     const size_t bn = (size_t)env * T.N, be = (size_t)env * T.E;
+    const bool mr = A.mu_out && T.has_pairs;
+    const bool fast = (T.N & 3) == 0 && (T.E & 15) == 0 && T.N <= 64 && T.E <= 128;
+    if (fast) {
+      const int nn = T.N >> 2, ne = T.E >> 2, nc = T.E >> 4;
+      tb_u4 vy[NIT], vs[EIT], vq[EIT], vr[EIT], vc[(EIT + 3) / 4], vd[2 * NIT], vu[NIT], vw[NIT];
+      out_load<NIT>(ysh(T), nn, vy);
+      out_load<EIT>(secsh(T), ne, vs);
+      out_load<EIT>(oq0(T), ne, vq);
+      out_load<EIT>(osr(T), ne, vr);
+      out_load<(EIT + 3) / 4>(ocomp(T), nc, vc);
+      out_load<2 * NIT>(odisp(T), 2 * nn, vd);
+      if (mr) {
+        out_load<NIT>(omu(T), nn, vu);
+        out_load<NIT>(omd(T), nn, vw);
+      }
+      out_store<NIT>(A.y_out + bn, nn, vy);
+      if (A.sec_out) out_store<EIT>(A.sec_out + be, ne, vs);
+      out_store<EIT>(A.q0 + be, ne, vq);
+      out_store<EIT>(A.sr + be, ne, vr);
+      out_store<(EIT + 3) / 4>(A.comp + be, nc, vc);
+      out_store<2 * NIT>(A.disp + bn * 2, 2 * nn, vd);
+      if (mr) {
+        out_store<NIT>(A.mu_out + bn, nn, vu);
+        out_store<NIT>(A.md_out + bn, nn, vw);
+      }
+      return;
+    }
     store_row(A.y_out + bn, ysh(T), 4 * T.N);
     if (A.sec_out) store_row(A.sec_out + be, secsh(T), 4 * T.E);
     store_row(A.q0 + be, oq0(T), 4 * T.E);
     store_row(A.sr + be, osr(T), 4 * T.E);
     store_row(A.comp + be, ocomp(T), T.E);
     store_row(A.disp + bn * 2, odisp(T), 8 * T.N);
-    if (A.mu_out && T.has_pairs) {
+    if (mr) {
       store_row(A.mu_out + bn, omu(T), 4 * T.N);
       store_row(A.md_out + bn, omd(T), 4 * T.N);
     }
   }
 
-  // ---- phase 8: one lane per env folds the partials (fixed order) and writes point ----
+  // ---- phase 8: six lanes per env each fold ONE quantity (fixed order) and write their share ----
+  //   lane 0: obj1 -> point[0], obj[0]   lane 1: obj2 -> point[1], obj[1]   lane 2: con1 -> point[2]
+  //   lane 3: con2 -> point[3]           lane 4: energy, reactions          lane 5: status
   TRUSS_HD void phase_finish(const TopoDev &T, const StepArgsDev &A) {
-    if (g != 0 || !active) return;
-    const double *RD = red(T);
-    double vol = 0.0, dt = 0.0, en = 0.0;
-    float c1 = 0.0f, c2 = 0.0f;
+    if (!active) return;
+    for (int q = g; q < 6; q += G) finish_one(T, A, q);
+  }
+  TRUSS_HD void finish_one(const TopoDev &T, const StepArgsDev &A, int q) {
+    const double *RD = red(T) + q * G;
+    double sum = 0.0, mx = 0.0;
     for (int j = 0; j < G; ++j) {
-      vol += RD[0 * G + j];
-      dt += RD[1 * G + j];
-      c1 = fmaxf(c1, (float)RD[2 * G + j]);
-      c2 = fmaxf(c2, (float)RD[3 * G + j]);
-      en += RD[4 * G + j];
-      if (RD[5 * G + j] != 0.0) bad = 1;
+      const double v = RD[j];
+      sum += v;
+      mx = v > mx ? v : mx;
     }
-    float obj1 = (float)vol, obj2 = (float)dt;
     float *pt = A.point + (size_t)env * 4;
-    pt[0] = obj1 / int1;
-    pt[1] = obj2 / int2;
-    pt[2] = c1;
-    pt[3] = c2;
-    if (A.obj) {
-      A.obj[(size_t)env * 2 + 0] = obj1;
-      A.obj[(size_t)env * 2 + 1] = obj2;
+    if (q == 0) {
+      const float obj1 = (float)sum;
+      pt[0] = obj1 / int1;
+      if (A.obj) A.obj[(size_t)env * 2 + 0] = obj1;
+    } else if (q == 1) {
+      const float obj2 = (float)sum;
+      pt[1] = obj2 / int2;
+      if (A.obj) A.obj[(size_t)env * 2 + 1] = obj2;
+    } else if (q == 2) {
+      pt[2] = (float)mx;
+    } else if (q == 3) {
+      pt[3] = (float)mx;
+    } else if (q == 4) {
+      if (A.energy) A.energy[env] = 0.5 * sum;
+      if (A.react) {
+        const double *RB = rbuf(T);
+        for (int i = 0; i < T.n_rest; ++i) A.react[(size_t)env * T.n_rest + i] = RB[i];
+      }
+    } else {
+      if (A.status) A.status[env] = sum != 0.0 ? 1 : 0;
     }
-    if (A.energy) A.energy[env] = 0.5 * en;
-    if (A.react) {
-      const double *RB = rbuf(T);
-      for (int i = 0; i < T.n_rest; ++i) A.react[(size_t)env * T.n_rest + i] = RB[i];
-    }
-    if (A.status) A.status[env] = bad;
   }
 };
 
@@ -941,7 +998,9 @@ struct StepLane {
   if ((T).n_sym_elems > 0 && !((A).flags & TB_NO_DECODE)) { PH(phase_sym_elems(T)); } \
   TRUSS_ST(3);                                                                      \
   PH(phase_elements(T, A));                                                         \
+  TRUSS_ST(10);                                                                     \
   PH(phase_assemble_nodes(T));                                                      \
+  TRUSS_ST(11);                                                                     \
   PH(solver_scratch_init(T));                                                       \
   TRUSS_ST(4);                                                                      \
   PH(solver_init(T));                                                               \
@@ -1005,6 +1064,7 @@ struct StepLane {
   PH(phase_post_nodes(T, A));                                                       \
   TRUSS_ST(8);                                                                      \
   PH_NS(phase_store(T, A));                                                         \
+  TRUSS_ST(12);                                                                     \
   PH_NS(phase_finish(T, A));                                                        \
   TRUSS_ST(9);
 

@@ -392,7 +392,21 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
       }
   }
   size_t o_ar = tb_push(blob, area), o_isr = tb_push(blob, isr);
-  size_t o_ad = tb_push(blob, adj8), o_do = tb_push(blob, diagoff);
+  // load code of every z/P slot in team frames (see TopoDev::f_zcode)
+  std::vector<uint8_t> zcode((size_t)zlen * nteams, 0);
+  for (int tm = 0; tm < nteams; ++tm)
+    for (int pz = 0; pz < zlen; ++pz) {
+      int orig = -1;
+      if (nteams == 1) orig = pz < n ? pz : -1;
+      else if (tm == 0) orig = pz < n - KA ? pz : -1;
+      else orig = pz < KA ? n - 1 - pz : -1;
+      if (orig < 0) continue;
+      int nd = posnode[orig];
+      if (nd < 0) continue;
+      uint8_t fl = nflags[nd >> 1];
+      zcode[(size_t)tm * zlen + pz] = (uint8_t)((nd & 1) | ((fl & TF_LOAD_BRIDGE) ? 2 : 0) | ((fl & TF_LOAD_ROOF) ? 4 : 0));
+    }
+  size_t o_ad = tb_push(blob, adj8), o_do = tb_push(blob, diagoff), o_zc = tb_push(blob, zcode);
   blob.resize((blob.size() + 15) & ~size_t(15));
   t->blob = tb_dev_alloc(blob.size());
   if (!t->blob || !tb_dev_upload(t->blob, blob.data(), blob.size())) {
@@ -426,6 +440,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.f_isr = (int32_t)o_isr;
   D.f_adj8 = (int32_t)o_ad;
   D.f_diagoff = (int32_t)o_do;
+  D.f_zcode = (int32_t)o_zc;
   D.nteams = nteams;
   D.KA = KA;
   D.mid = mid;
@@ -470,7 +485,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     size_t o0 = off;
     D.o_zs = carve(sizeof(double) * (size_t)zlen * nteams);
     D.o_dinv = carve(sizeof(double) * (size_t)dlen * nteams);
-    D.o_xsol = carve(sizeof(double) * (zslot + 1));
+    D.o_xsol = carve(sizeof(double) * (zslot + 2));
     D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
     D.o_zring = carve(sizeof(double) * 2 * W * nteams);
     D.o_ev = (int32_t)o0;
