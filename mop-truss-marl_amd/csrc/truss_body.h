@@ -622,7 +622,7 @@ struct StepLane {
     const double zk = ZRt[(k & 1) * W + kk];
     const double d = col[kk];
     const double inv = tb_rcp(d);  // d <= 0 / NaN is detected after the loop (pivot_check), off the chain
-    if (k < T.dlen) Dt[k] = inv;  // every lane of the team stores the same value
+    Dt[k] = inv;  // every lane of the team stores the same value
     Zt[k] = zk;            // z_k replaces P_k (P_k was consumed when row k entered the window)
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
@@ -713,7 +713,7 @@ struct StepLane {
       bc[slot][2 * i + 1] = v[1];
     }
     bz[slot] = Zt[kc];
-    bd[slot] = Dt[kc < T.dlen ? kc : 0];
+    bd[slot] = Dt[kc];
   }
   TRUSS_HD void backsub_step(const TopoDev &T, int k, int kk) {
     const int slot = kk & 1;
@@ -743,7 +743,7 @@ struct StepLane {
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       const int p = kb + j;
-      if (owns_row(T, p)) XS[orig_pos(T, team, p)] = xs[j];
+      XS[owns_row(T, p) ? orig_pos(T, team, p) : T.zslot + 1] = xs[j];  // rows of the other team: dummy slot
     }
   }
   // mid-block variant used right after the middle block: slot j holds the window row win_row(j)
@@ -752,7 +752,7 @@ struct StepLane {
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       const int p = win_row(T, j);
-      if (team == 0 && owns_row(T, p)) XS[p] = xs[j];
+      XS[(team == 0 && owns_row(T, p)) ? p : T.zslot + 1] = xs[j];
     }
   }
   // team B picks up the middle solutions (in its own frame) before it continues outwards

@@ -276,7 +276,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     rowsA = KA + 2 * W;
     rowsB = KA + W;
     zlen = KA + 2 * W;
-    dlen = KA + W;
+    dlen = KA + 2 * W;
     zslot = n + 2 * W;
   } else {
     KA = t->n_pad;
@@ -284,7 +284,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     rowsA = t->n_pad + W;
     rowsB = 0;
     zlen = t->n_pad + W;
-    dlen = t->n_pad;
+    dlen = t->n_pad + W;
     zslot = t->n_pad;
   }
   // band offset (in doubles) of the lower-band entry (r, c), r >= c, original solver positions
@@ -485,7 +485,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     size_t o0 = off;
     D.o_zs = carve(sizeof(double) * (size_t)zlen * nteams);
     D.o_dinv = carve(sizeof(double) * (size_t)dlen * nteams);
-    D.o_xsol = carve(sizeof(double) * (zslot + 2));
+    D.o_xsol = carve(sizeof(double) * (zslot + 4));  // + zero slot, dummy slot, 16-byte fill
     D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
     D.o_zring = carve(sizeof(double) * 2 * W * nteams);
     D.o_ev = (int32_t)o0;
@@ -511,6 +511,12 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.env_stride = (int32_t)stride;
   D.o_env0 = (int32_t)((blob.size() + 255) & ~size_t(255));
   t->lds_bytes = D.o_env0 + stride * (64 / t->G);
+  if (tb_env_int("TRUSS_VERBOSE", 0))
+    fprintf(stderr,
+            "[truss_mi355] N=%d E=%d ndof=%d bw=%d | G=%d WL=%d RPL=%d EPL=%d teams=%d KA=%d mid=%d | tables %d B, "
+            "env %zu B, LDS/workgroup %zu B (%zu workgroups/CU)\n",
+            N, E, t->ndof, t->bw, t->G, t->WL, t->RPL, t->EPL, nteams, KA, mid, D.blob_bytes, stride, t->lds_bytes,
+            (size_t)(160 * 1024) / t->lds_bytes);
   if (t->lds_bytes > 160 * 1024) {
     tb_dev_free(t->blob);
     delete t;
