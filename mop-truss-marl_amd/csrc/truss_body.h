@@ -143,7 +143,7 @@ struct StepLane {
   static constexpr int NT = G / WL;   // solver teams per env (1, or 2 = two-sided elimination)
 
   int lane, g, gs, team, env, envc;
-  double *Kt, *Zt, *Dt, *ZRt;  // this lane's team: band rows, z / P vector, 1/d, broadcast ring
+  double *Kt, *Zt, *ZRt;  // this lane's team: band rows, {z or P, 1/d} pairs, broadcast ring
   bool active;
   const char *TB;  // LDS copy of the topology blob
   char *L;         // this env's LDS region
@@ -205,8 +205,7 @@ struct StepLane {
     TB = lds;
     L = lds + T.o_env0 + (size_t)grp * T.env_stride;
     Kt = (double *)(L + T.o_kb) + team * T.rowsA * W;
-    Zt = (double *)(L + T.o_zs) + team * T.zlen;
-    Dt = (double *)(L + T.o_dinv) + team * T.dlen;
+    Zt = (double *)(L + T.o_zs) + team * 2 * T.zlen;
     ZRt = (double *)(L + T.o_zring) + team * 2 * W;
     bad = 0;
     p_vol = p_dt = p_en = 0.0;
@@ -564,8 +563,8 @@ struct StepLane {
     // identity rows: team A beyond its part + middle; team B beyond the middle (its middle rows keep a
     // zero diagonal: they are never pivots of team B)
     const int idA = T.nteams == 1 ? T.ndof : T.ndof - T.KA;
-    for (int r = idA + g; r < T.rowsA; r += G) K[r * W] = 1.0;
-    for (int r = T.KA + T.mid + g; r < T.rowsB; r += G) K[(T.rowsA + r) * W] = 1.0;
+    for (int r = idA + g; r < T.rowsA; r += G) K[r * W + r % W] = 1.0;
+    for (int r = T.KA + T.mid + g; r < T.rowsB; r += G) K[(T.rowsA + r) * W + r % W] = 1.0;
   }
 
   // ---- phase 5b: the element-value buffer is dead; its bytes become the solver scratch ----
@@ -575,7 +574,7 @@ struct StepLane {
     const int lbit = is_roof ? 4 : 2;
     for (int r = g; r < T.zlen * T.nteams; r += G) {   // load vector P in each team's frame (host table)
       const int c = ZC[r];
-      Z[r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
+      Z[2 * r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
     }
     tb_d2 *X2 = (tb_d2 *)__builtin_assume_aligned(xsol(T), 16);
     const tb_d2 z2 = {0.0, 0.0};
@@ -593,8 +592,8 @@ struct StepLane {
     for (int s = 0; s < RPL; ++s) {
       int r = gs + WL * s;
 #pragma unroll
-      for (int c = 0; c < W; ++c) R[s][c] = (c <= r) ? Kt[r * W + (r - c)] : Kt[c * W + (c - r)];
-      rhs[s] = Zt[r];
+      for (int c = 0; c < W; ++c) R[s][c] = (c <= r) ? Kt[r * W + c] : Kt[c * W + r];  // band rows are stored by column residue
+      rhs[s] = Zt[2 * r];
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) xs[j] = 0.0;
@@ -622,8 +621,11 @@ struct StepLane {
     const double zk = ZRt[(k & 1) * W + kk];
     const double d = col[kk];
     const double inv = tb_rcp(d);  // d <= 0 / NaN is detected after the loop (pivot_check), off the chain
-    Dt[k] = inv;  // every lane of the team stores the same value
-    Zt[k] = zk;            // z_k replaces P_k (P_k was consumed when row k entered the window)
+    {  // {z_k, 1/d_k} in one 16-byte store (every lane of the team: same values); z_k replaces P_k,
+       // which was consumed when row k entered the window
+      tb_d2 zd = {zk, inv};
+      ((tb_d2 *)__builtin_assume_aligned(Zt, 16))[k] = zd;
+    }
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
       double l = R[s][kk] * inv;
@@ -632,26 +634,22 @@ struct StepLane {
         if (j != kk) R[s][j] = fma(-l, col[j], R[s][j]);
       rhs[s] = fma(-l, zk, rhs[s]);
     }
-    // the window slides: column k leaves, column k+W enters; the pivot row's lane adopts row k+W
+    // the window slides: column k leaves, column k+W enters; the pivot row's lane adopts row k+W.
+    // Band rows are stored by column residue (entry (r, c) at r*W + c%W), so a row loads straight into
+    // the window registers and every other lane finds its entry of the new column at its own residue.
     const int rn = k + W;
     const double *Kn = Kt + rn * W;
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) {
-      int o = (gs + WL * s - kk + W) % W;  // this row is k+o; it needs K[k+W][k+o] = band entry W-o
-      R[s][kk] = Kn[(W - o) % W];
-    }
+    for (int s = 0; s < RPL; ++s) R[s][kk] = Kn[gs + WL * s];
     if (gs == kk % WL) {
       const int sp = kk / WL;
-      double nr[W];
 #pragma unroll
       for (int i = 0; i < W / 2; ++i) {
         tb_d2 v = ((const tb_d2 *)__builtin_assume_aligned(Kn, 16))[i];
-        nr[2 * i] = v[0];
-        nr[2 * i + 1] = v[1];
+        R[sp][2 * i] = v[0];
+        R[sp][2 * i + 1] = v[1];
       }
-#pragma unroll
-      for (int j = 1; j < W; ++j) R[sp][(kk + j) % W] = nr[W - j];
-      rhs[sp] = Zt[rn];
+      rhs[sp] = Zt[2 * rn];
     }
   }
 
@@ -661,7 +659,7 @@ struct StepLane {
   TRUSS_HD void pivot_check(const TopoDev &T) {
     const int lim = (T.nteams == 2 && team == 1) ? T.KA : (T.nteams == 2 ? T.KA + W : T.KA);
     for (int k = gs; k < lim; k += WL) {
-      const double v = Dt[k];
+      const double v = Zt[2 * k + 1];
       if (!(v > 0.0) || !(v < 1.7e308)) bad = 1;
     }
   }
@@ -712,8 +710,11 @@ struct StepLane {
       bc[slot][2 * i] = v[0];
       bc[slot][2 * i + 1] = v[1];
     }
-    bz[slot] = Zt[kc];
-    bd[slot] = Dt[kc];
+    {
+      tb_d2 zd = ((const tb_d2 *)__builtin_assume_aligned(Zt, 16))[kc];
+      bz[slot] = zd[0];
+      bd[slot] = zd[1];
+    }
   }
   TRUSS_HD void backsub_step(const TopoDev &T, int k, int kk) {
     const int slot = kk & 1;

@@ -287,11 +287,13 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     dlen = t->n_pad + W;
     zslot = t->n_pad;
   }
-  // band offset (in doubles) of the lower-band entry (r, c), r >= c, original solver positions
+  // offset (in doubles) of the lower-band entry (r, c), r >= c, original solver positions.  A band row
+  // stores its W entries by COLUMN RESIDUE in the owning team's frame: entry (row, col) at row*W + col%W
+  // (distinct for the W consecutive columns of a row), which is the order of the solver's window registers.
   auto band_off = [&](int r, int c) -> int {
-    if (nteams == 1 || r < n - KA) return r * W + (r - c);              // team A: its part + middle rows
+    if (nteams == 1 || r < n - KA) return r * W + (c % W);              // team A: its part + middle rows
     int rb = n - 1 - r, cb = n - 1 - c;                                    // team B frame: cb >= rb
-    return (rowsA + cb) * W + (cb - rb);
+    return (rowsA + cb) * W + (rb % W);
   };
 
   // solver position -> reference DOF (0-based) and node*2+comp
@@ -483,8 +485,8 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   // the back substitution `red` (objective partials) reuses the z vectors
   {
     size_t o0 = off;
-    D.o_zs = carve(sizeof(double) * (size_t)zlen * nteams);
-    D.o_dinv = carve(sizeof(double) * (size_t)dlen * nteams);
+    D.o_zs = carve(sizeof(double) * 2 * (size_t)zlen * nteams);  // {z or P, 1/d} pairs
+    D.o_dinv = D.o_zs;
     D.o_xsol = carve(sizeof(double) * (zslot + 4));  // + zero slot, dummy slot, 16-byte fill
     D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
     D.o_zring = carve(sizeof(double) * 2 * W * nteams);
