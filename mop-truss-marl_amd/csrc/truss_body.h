@@ -86,7 +86,8 @@ struct TopoDev {
   int32_t f_nflags;    // uint8 [N]
   int32_t f_dofpos;    // int16 [N][2]   solver position of (node, comp) or -1 when restrained
   int32_t f_restslot;  // int16 [N][2]   reaction slot (reference order nsc-ndof-1) or -1
-  int32_t f_asm;       // int16 [E][10]  (band offset << 3) | (type << 1) | negate, or -1
+  int32_t f_asm;       // int16 [E][4]   band offsets of the element's four off-diagonal entries
+                       //                (ax,bx) -cc, (ay,by) -ss, (ax,by) -cs, (ay,bx) -cs; -1 = restrained
   int32_t f_diagoff;   // int16 [N][3]   band offsets of (x,x), (y,y), (x,y) of the node block, or -1
   int32_t f_zcode;     // uint8 [nteams*zlen] load code of every z/P slot: bit0 comp (0 x, 1 y), bit1 loaded (bridge), bit2 loaded (roof)
   int32_t f_posnode;   // int16 [n_pad]  node*2+comp at solver position, -1 = padding row
@@ -197,7 +198,7 @@ struct StepLane {
     lane = lane_;
     g = lane % G;
     gs = g % WL;
-    team = T.nteams == 2 ? g / WL : 0;  // one team: lanes beyond WL mirror lanes 0..WL-1
+    team = T.nteams == 2 ? (g / WL) & 1 : 0;  // lanes beyond the team(s) mirror lanes 0..nteams*WL-1
     int grp = lane / G;
     env = block * EPB + grp;
     active = env < A.B;
@@ -529,12 +530,12 @@ struct StepLane {
         EV[3 * e + 0] = kcc[i];
         EV[3 * e + 1] = kcs[i];
         EV[3 * e + 2] = kss[i];
-        const int16_t *code = AC + e * 10 + 6;
+        const int16_t *code = AC + e * 4;
         const int c0 = code[0], c1 = code[1], c2 = code[2], c3 = code[3];
-        if (c0 >= 0) K[c0 >> 3] = -kcc[i];
-        if (c1 >= 0) K[c1 >> 3] = -kss[i];
-        if (c2 >= 0) K[c2 >> 3] = -kcs[i];
-        if (c3 >= 0) K[c3 >> 3] = -kcs[i];
+        if (c0 >= 0) K[c0] = -kcc[i];
+        if (c1 >= 0) K[c1] = -kss[i];
+        if (c2 >= 0) K[c2] = -kcs[i];
+        if (c3 >= 0) K[c3] = -kcs[i];
       }
     }
   }

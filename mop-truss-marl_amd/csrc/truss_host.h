@@ -30,7 +30,7 @@ struct TbVariant {
   int G, WL, RPL, EPL;  // lanes per env, window lanes, rows per lane, elements per lane
 };
 #define TRUSS_VARIANTS(X) \
-  X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(8, 8, 2, 10) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20)
+  X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(8, 8, 2, 10) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20)
 static const TbVariant kVariants[] = {
 #define X(g, wl, r, e) {g, wl, r, e},
     TRUSS_VARIANTS(X)
@@ -268,7 +268,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   t->n_pad = ((t->ndof + W - 1) / W) * W;
   // ---- solver geometry (see TopoDev) ----
   const int n = t->ndof;
-  const int nteams = (t->G / t->WL == 2 && t->RPL == 1 && !tb_env_int("TRUSS_ONE_SIDED", 0)) ? 2 : 1;
+  const int nteams = (t->G / t->WL >= 2 && t->RPL == 1 && !tb_env_int("TRUSS_ONE_SIDED", 0)) ? 2 : 1;
   int KA, mid, rowsA, rowsB, zlen, dlen, zslot;
   if (nteams == 2) {
     KA = n > W ? (n - W + 1) / 2 : 0;
@@ -308,33 +308,34 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
       restslot[i] = (int16_t)(t->nsc[i] - t->ndof - 1);
     }
   }
-  // assembly codes (FEM_2Dtruss.py:320-324 restricted to the lower band)
-  std::vector<int16_t> asm_code(10 * (size_t)E, -1);
+  // band offsets of every element's four off-diagonal entries (FEM_2Dtruss.py:320-324 restricted to the
+  // lower band); the node-diagonal blocks go through `diagoff` below
+  std::vector<int16_t> asm_code(4 * (size_t)E, -1);
   bool band_ok = true;
   for (int e = 0; e < E; ++e) {
     int a = conn[2 * e], b = conn[2 * e + 1];
     int pa[2] = {dofpos[2 * a], dofpos[2 * a + 1]}, pb[2] = {dofpos[2 * b], dofpos[2 * b + 1]};
     int cnt = 0;
-    auto add = [&](int r, int c, int type, int neg) {
+    auto add = [&](int r, int c) {
       int code = -1;
       if (r >= 0 && c >= 0) {
         if (r < c) std::swap(r, c);
         if (r - c >= W) band_ok = false;
-        code = (band_off(r, c) << 3) | (type << 1) | neg;
+        code = band_off(r, c);
         if (code > 32767) band_ok = false;
       }
-      asm_code[10 * (size_t)e + cnt++] = (int16_t)code;
+      asm_code[4 * (size_t)e + cnt++] = (int16_t)code;
     };
-    add(pa[0], pa[0], 0, 0);
-    add(pa[1], pa[1], 2, 0);
-    add(pa[0], pa[1], 1, 0);
-    add(pb[0], pb[0], 0, 0);
-    add(pb[1], pb[1], 2, 0);
-    add(pb[0], pb[1], 1, 0);
-    add(pa[0], pb[0], 0, 1);
-    add(pa[1], pb[1], 2, 1);
-    add(pa[0], pb[1], 1, 1);
-    add(pa[1], pb[0], 1, 1);
+    add(pa[0], pb[0]);
+    add(pa[1], pb[1]);
+    add(pa[0], pb[1]);
+    add(pa[1], pb[0]);
+    for (int i = 0; i < 2; ++i)   // the node's own x/y pair must fit the band too
+      for (int j = 0; j < 2; ++j) {
+        const int *pp = i ? pb : pa;
+        if (pp[0] >= 0 && pp[1] >= 0 && std::abs(pp[0] - pp[1]) >= W) band_ok = false;
+        (void)j;
+      }
   }
   if (!band_ok) {
     delete t;
