@@ -523,20 +523,20 @@ struct StepLane {
     const int16_t *AC = t_asm(T);
     double *EV = evsh(T);
     if (g == 0) EV[3 * T.E] = EV[3 * T.E + 1] = EV[3 * T.E + 2] = 0.0;  // slot the padded adjacency points at
+    // branch-free: a lane index past the last element redoes element E-1 (same values to the same
+    // places), entries on restrained DOFs go to a trash slot behind the band
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
       const int e = g + G * i;
-      if (e < T.E) {
-        EV[3 * e + 0] = kcc[i];
-        EV[3 * e + 1] = kcs[i];
-        EV[3 * e + 2] = kss[i];
-        const int16_t *code = AC + e * 4;
-        const int c0 = code[0], c1 = code[1], c2 = code[2], c3 = code[3];
-        if (c0 >= 0) K[c0] = -kcc[i];
-        if (c1 >= 0) K[c1] = -kss[i];
-        if (c2 >= 0) K[c2] = -kcs[i];
-        if (c3 >= 0) K[c3] = -kcs[i];
-      }
+      const int ee = e < T.E ? e : T.E - 1;
+      EV[3 * ee + 0] = kcc[i];
+      EV[3 * ee + 1] = kcs[i];
+      EV[3 * ee + 2] = kss[i];
+      const int16_t *code = AC + ee * 4;
+      K[code[0]] = -kcc[i];
+      K[code[1]] = -kss[i];
+      K[code[2]] = -kcs[i];
+      K[code[3]] = -kcs[i];
     }
   }
 
@@ -556,10 +556,9 @@ struct StepLane {
         cs += EV[3 * e + 1];
         ss += EV[3 * e + 2];
       }
-      const int o0 = DO[3 * n], o1 = DO[3 * n + 1], o2 = DO[3 * n + 2];
-      if (o0 >= 0) K[o0] = cc;
-      if (o1 >= 0) K[o1] = ss;
-      if (o2 >= 0) K[o2] = cs;
+      K[DO[3 * n]] = cc;      // restrained DOFs point at the trash slot
+      K[DO[3 * n + 1]] = ss;
+      K[DO[3 * n + 2]] = cs;
     }
     // identity rows: team A beyond its part + middle; team B beyond the middle (its middle rows keep a
     // zero diagonal: they are never pivots of team B)

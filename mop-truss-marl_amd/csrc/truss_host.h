@@ -296,6 +296,8 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     return (rowsA + cb) * W + (rb % W);
   };
 
+  const int trash_off = (rowsA + rowsB) * W;  // a spare double right behind the band: sink for entries on restrained DOFs
+
   // solver position -> reference DOF (0-based) and node*2+comp
   t->perm.assign(t->ndof, -1);
   std::vector<int16_t> posnode(t->n_pad, -1), dofpos16(2 * N, -1), restslot(2 * N, -1);
@@ -317,7 +319,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     int pa[2] = {dofpos[2 * a], dofpos[2 * a + 1]}, pb[2] = {dofpos[2 * b], dofpos[2 * b + 1]};
     int cnt = 0;
     auto add = [&](int r, int c) {
-      int code = -1;
+      int code = trash_off;
       if (r >= 0 && c >= 0) {
         if (r < c) std::swap(r, c);
         if (r - c >= W) band_ok = false;
@@ -342,7 +344,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     return tb_fail(TRUSS_EUNSUPPORTED, "internal: band wider than window / offsets beyond int16");
   }
   // band offsets of the node-diagonal 2x2 block entries (x,x), (y,y), (x,y)
-  std::vector<int16_t> diagoff(3 * (size_t)N, -1);
+  std::vector<int16_t> diagoff(3 * (size_t)N, (int16_t)trash_off);
   for (int nd = 0; nd < N; ++nd) {
     int px = dofpos[2 * nd], py = dofpos[2 * nd + 1];
     if (px >= 0) diagoff[3 * nd + 0] = (int16_t)band_off(px, px);
@@ -463,7 +465,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   };
   // band region; after the back substitution it is reused as the output staging area
   {
-    size_t band = sizeof(double) * (size_t)(rowsA + rowsB) * W;
+    size_t band = sizeof(double) * ((size_t)(rowsA + rowsB) * W + 2);  // + trash slot
     size_t so = 0;
     auto sub = [&](size_t bytes) {
       size_t o = so;
