@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time the E=76 topology and the obs kernel")
+    ap.add_argument("--lib", default=None, help="diagnostic: another HIP build of the same ABI (default: the product library)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +103,8 @@ def main():
 
     import truss_mi355 as tm
     from truss_mi355 import synthetic, distributed
-    lib = tm.load()                      # raises if the HIP extension is missing
+    lib = tm.load(args.lib)              # raises if the HIP extension is missing
+    assert lib.backend == "hip", "bench.py measures the HIP path only"
     topo = synthetic.bench_topology(NUM_X, N_EXTRA)
     B = args.envs
     env, G, T, _ = distributed.make_rank_env(topo, B, rank, device=dev, lib=lib, seed=1234,

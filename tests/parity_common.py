@@ -21,8 +21,10 @@ def build_emu():
             os.path.join(ROOT, "mop-truss-marl_amd", "csrc", "truss_host.h"),
             os.path.join(ROOT, "include", "truss_mi355.h")]
     if (not os.path.exists(EMU_LIB)) or any(os.path.getmtime(d) > os.path.getmtime(EMU_LIB) for d in deps):
+        # TRUSS_EMU_CXXFLAGS: e.g. -DTRUSS_PIPELINE=1 to emulate the alternative factorisation schedule
+        extra = os.environ.get("TRUSS_EMU_CXXFLAGS", "").split()
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                               "-Wno-unknown-pragmas", "-o", EMU_LIB, src], cwd=EMU_DIR)
+                               "-Wno-unknown-pragmas"] + extra + ["-o", EMU_LIB, src], cwd=EMU_DIR)
     return EMU_LIB
 
 

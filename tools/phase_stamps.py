@@ -20,6 +20,8 @@ NAMES = ["stage (HBM->LDS)", "decode", "sizing", "elements+assembly", "factorisa
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     path = os.path.join(ROOT, "mop-truss-marl_amd", "csrc", "libtruss_mi355_diag.so")
+    if len(sys.argv) > 2:
+        path = os.path.abspath(sys.argv[2])   # e.g. an ablated build from tools/ablate.sh
     lib = tm.load(path)
     lib.dll.truss_debug_stamps.argtypes = [ctypes.c_void_p]
     for label, topo in (("32n/80e", synthetic.bench_topology(16, 4)),):
@@ -45,6 +47,9 @@ def main():
             sub = np.array(list(st), dtype=np.float64)
             extra = extra + np.array([sub[10] - sub[3], sub[11] - sub[10], sub[4] - sub[11], sub[12] - sub[8], sub[9] - sub[12]])
         acc /= 10
+        if len(sys.argv) > 2:
+            print(f"{os.path.basename(path):28s} total {acc.sum():7.0f} | " + " ".join(f"{c:6.0f}" for c in acc))
+            continue
         print(f"== {label} B={B}  {topo.solver_info(lib)['lanes_per_env']} lanes/env, total {acc.sum():.0f} cycles")
         for n, c in zip(NAMES, acc):
             print(f"   {n:22s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f} %")
