@@ -139,6 +139,7 @@ TRUSS_HD float tb_round2(float v) { return rintf(v * 100.0f) / 100.0f; }
 template <int G, int WL, int RPL, int EPL>
 struct StepLane {
   static constexpr int W = WL * RPL;
+  static constexpr int WL_ = WL;
   static constexpr int EPB = 64 / G;  // envs per wave
   static constexpr int NDEG = 8;      // unrolled node-degree bound of the diagonal gather
   static constexpr int NT = G / WL;   // solver teams per env (1, or 2 = two-sided elimination)
@@ -694,47 +695,68 @@ struct StepLane {
     }
   }
 
-  // back substitution, every lane of the team redundantly:
+  // back substitution, distributed over the lanes of the team:
   //   x_k = (z_k - sum_m A[k+m,k] x_{k+m}) / d_k
-  //  * the coefficients of step k-1 are fetched from LDS (into the other register slot) BEFORE step k's
-  //    arithmetic, so the LDS latency overlaps the FMA chain instead of preceding it;
-  //  * the terms are accumulated oldest-x first in two partial sums: only one fma and one multiply
-  //    depend on the x_{k+1} the previous step has just produced.
-  double bc[2][W], bz[2], bd[2];
-  TRUSS_HD void backsub_prefetch(const TopoDev &T, int k, int slot) {
-    const int kc = k < 0 ? 0 : k;
-    const tb_d2 *K2 = (const tb_d2 *)__builtin_assume_aligned(Kt + kc * W, 16);
+  // Row k of the factor (the posted pivot column k, {z_k, 1/d_k}) is needed by ONE dot product.  Each
+  // lane therefore loads only the rows it owns -- row kb + gs (+ WL s) of a block of W steps, one set of
+  // loads per block instead of one per step and lane -- evaluates every step's dot product with its own
+  // row (only the owner's result means anything), and the owner's x_k reaches the other lanes of the
+  // team through a DPP row broadcast: registers only, no LDS round trip in the chain of dependent
+  // solutions.  (All lanes reading every row was 5 ds_read_b128 per step and wave: the LDS, shared by the
+  // four waves of a CU, was the bottleneck of this phase.)
+  //  * the terms are accumulated oldest-x first in two partial sums: only one fma, one multiply and the
+  //    broadcast depend on the x_{k+1} the previous step has just produced;
+  //  * the rows of the next block are requested while the current block is being solved.
+  double bc[RPL][W], bz[RPL], bd[RPL];   // rows owned in the current block
+  double nc[RPL][W], nz[RPL], nd[RPL];   // ... in the next block (in flight)
+  double bx;                             // this lane's candidate for x_k (valid in the owner lane)
+  double myx[RPL] = {};                  // x of the rows this lane owns in the current block
+  StepLane *peers = nullptr;             // emulator only: the 64 lanes of the wave (DPP stand-in)
+  TRUSS_HD void backsub_rows_fetch(const TopoDev &T, int kb) {
 #pragma unroll
-    for (int i = 0; i < W / 2; ++i) {
-      tb_d2 v = K2[i];
-      bc[slot][2 * i] = v[0];
-      bc[slot][2 * i + 1] = v[1];
+    for (int s = 0; s < RPL; ++s) {
+      const int p = kb + gs + WL * s;
+      const int pc = p < 0 ? 0 : p;
+      const tb_d2 *K2 = (const tb_d2 *)__builtin_assume_aligned(Kt + pc * W, 16);
+#pragma unroll
+      for (int i = 0; i < W / 2; ++i) {
+        tb_d2 v = K2[i];
+        nc[s][2 * i] = v[0];
+        nc[s][2 * i + 1] = v[1];
+      }
+      tb_d2 zd = ((const tb_d2 *)__builtin_assume_aligned(Zt, 16))[pc];
+      nz[s] = zd[0];
+      nd[s] = zd[1];
     }
-    {
-      tb_d2 zd = ((const tb_d2 *)__builtin_assume_aligned(Zt, 16))[kc];
-      bz[slot] = zd[0];
-      bd[slot] = zd[1];
+  }
+  TRUSS_HD void backsub_rows_adopt() {
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) bc[s][j] = nc[s][j];
+      bz[s] = nz[s];
+      bd[s] = nd[s];
     }
   }
   TRUSS_HD void backsub_step(const TopoDev &T, int k, int kk) {
-    const int slot = kk & 1;
-    backsub_prefetch(T, k - 1, slot ^ 1);
-    TB_SCHED_FENCE();
-    double acc0 = bz[slot], acc1 = 0.0;
+    const int s = kk / WL;
+    double acc0 = bz[s], acc1 = 0.0;
 #pragma unroll
     for (int m = W - 1; m >= 2; --m) {  // rows k+m, m = W-1 .. 2 (older solutions)
       const int j = (kk + m) % W;
-      if (m & 1) acc1 = fma(-bc[slot][j], xs[j], acc1);
-      else acc0 = fma(-bc[slot][j], xs[j], acc0);
+      if (m & 1) acc1 = fma(-bc[s][j], xs[j], acc1);
+      else acc0 = fma(-bc[s][j], xs[j], acc0);
     }
     const int jn = (kk + 1) % W;        // row k+1: the newest solution
-    double acc = fma(-bc[slot][jn], xs[jn], acc0 + acc1);
-    double xk = acc * bd[slot];
-    xs[kk] = xk;
+    double acc = fma(-bc[s][jn], xs[jn], acc0 + acc1);
+    bx = acc * bd[s];
   }
-  // after a block of W steps: xs[j] is x of team-frame row kb + j.  Stored once per block so the LDS
-  // loads of the next steps are not fenced behind a may-alias store after every step.  Team B's slots
-  // of the middle block (kb + j >= KA) were solved by team A and are not written by team B.
+  TRUSS_HD void backsub_share(int kk) {
+    xs[kk] = tb_team_bcast(*this, kk % WL);
+    if (gs == kk % WL) myx[kk / WL] = bx;   // the owner keeps x_k for the block's store
+  }
+  // after a block of W steps the owners store their solutions (team-frame rows kb + gs + WL s).  Team B's
+  // rows of the middle block (>= KA) were solved by team A and are not written by team B.
   TRUSS_HD bool owns_row(const TopoDev &T, int p) const {
     if (T.nteams == 1) return true;
     return team == 0 ? p < T.ndof - T.KA : p < T.KA;   // A: its part + the middle; B: its part
@@ -742,19 +764,16 @@ struct StepLane {
   TRUSS_HD void backsub_flush(const TopoDev &T, int kb) {
     double *XS = xsol(T);
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const int p = kb + j;
-      XS[owns_row(T, p) ? orig_pos(T, team, p) : T.zslot + 1] = xs[j];  // rows of the other team: dummy slot
+    for (int s = 0; s < RPL; ++s) {   // every lane stores the rows it owns: one store per block, not W
+      const int p = kb + gs + WL * s;
+      XS[owns_row(T, p) ? orig_pos(T, team, p) : T.zslot + 1] = myx[s];  // rows of the other team: dummy slot
     }
   }
-  // mid-block variant used right after the middle block: slot j holds the window row win_row(j)
+  // mid-block variant used right after the middle block: lane gs owns the window row win_row(gs)
   TRUSS_HD void backsub_flush_mid(const TopoDev &T) {
     double *XS = xsol(T);
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const int p = win_row(T, j);
-      XS[(team == 0 && owns_row(T, p)) ? p : T.zslot + 1] = xs[j];
-    }
+    const int p = win_row(T, gs);
+    XS[(team == 0 && owns_row(T, p)) ? p : T.zslot + 1] = myx[0];
   }
   // team B picks up the middle solutions (in its own frame) before it continues outwards
   TRUSS_HD void backsub_reload(const TopoDev &T) {
@@ -1017,6 +1036,7 @@ struct StepLane {
         PH_NS(pivot_update(T, kb_ + kk_, kk_));                                     \
       }                                                                             \
     }                                                                               \
+    TRUSS_ST(13);                                                                   \
     for (; kb_ < kend_; kb_ += W_) {                                                \
       TRUSS_UNROLL                                                                  \
       for (int kk_ = 0; kk_ < W_; ++kk_) {                                          \
@@ -1036,8 +1056,10 @@ struct StepLane {
     /* Back substitution, top block first.  Special (guarded) blocks: those that contain the first step \
        kend-1 or the hand-over step KA-1 of the two-sided scheme; everything below runs clean. */    \
     kb_ = ((kend_ - 1) / W_) * W_;                                                  \
-    if ((T).nteams == 1) { PH_NS(backsub_prefetch(T, kend_ - 1, (W_ - 1) & 1)); }   \
+    PH_NS(backsub_rows_fetch(T, kb_));                                              \
     for (; (T).nteams == 2 && kb_ >= 0 && kb_ + W_ - 1 >= (T).KA - 1; kb_ -= W_) {  \
+      PH_NS(backsub_rows_adopt());                                                  \
+      PH_NS(backsub_rows_fetch(T, kb_ - W_));                                       \
       TRUSS_UNROLL                                                                  \
       for (int kk_ = W_ - 1; kk_ >= 0; --kk_) {                                     \
         if (kb_ + kk_ < kend_) {                                                    \
@@ -1046,15 +1068,21 @@ struct StepLane {
             BAR();                                                                  \
             PH_NS(backsub_reload(T));                                               \
           }                                                                         \
-          if (kb_ + kk_ == kend_ - 1) { PH_NS(backsub_prefetch(T, kb_ + kk_, kk_ & 1)); } \
           PH_NS(backsub_step(T, kb_ + kk_, kk_));                                   \
+          PH_NS(backsub_share(kk_));                                                \
         }                                                                           \
       }                                                                             \
       PH_NS(backsub_flush(T, kb_));                                                 \
     }                                                                               \
+    TRUSS_ST(14);                                                                   \
     for (; kb_ >= 0; kb_ -= W_) {                                                   \
+      PH_NS(backsub_rows_adopt());                                                  \
+      PH_NS(backsub_rows_fetch(T, kb_ - W_));                                       \
       TRUSS_UNROLL                                                                  \
-      for (int kk_ = W_ - 1; kk_ >= 0; --kk_) { PH_NS(backsub_step(T, kb_ + kk_, kk_)); } \
+      for (int kk_ = W_ - 1; kk_ >= 0; --kk_) {                                     \
+        PH_NS(backsub_step(T, kb_ + kk_, kk_));                                     \
+        PH_NS(backsub_share(kk_));                                                  \
+      }                                                                             \
       PH_NS(backsub_flush(T, kb_));                                                 \
     }                                                                               \
   }                                                                                 \

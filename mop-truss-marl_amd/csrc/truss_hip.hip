@@ -19,6 +19,44 @@
 // LDS float64 scatter-add (ds_add_f64 on gfx950)
 __device__ __forceinline__ void tb_lds_add(double *p, double v) { unsafeAtomicAdd(p, v); }
 
+// Broadcast of a double from lane SRC of every WL-lane team to the lanes of that team, through the DPP
+// cross-lane path (no LDS): row_newbcast inside 16-lane rows, one bank-masked move per 8-lane half when
+// a row holds two teams; quad_perm for 4-lane teams.
+template <int WL, int SRC>
+__device__ __forceinline__ double tb_dpp_bcast(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int rlo, rhi;
+  if constexpr (WL == 16) {
+    rlo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + SRC, 0xf, 0xf, false);
+    rhi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + SRC, 0xf, 0xf, false);
+  } else if constexpr (WL == 8) {
+    rlo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + SRC, 0xf, 0x3, false);
+    rlo = __builtin_amdgcn_update_dpp(rlo, lo, 0x150 + 8 + SRC, 0xf, 0xc, false);
+    rhi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + SRC, 0xf, 0x3, false);
+    rhi = __builtin_amdgcn_update_dpp(rhi, hi, 0x150 + 8 + SRC, 0xf, 0xc, false);
+  } else {
+    static_assert(WL == 4, "team width");
+    constexpr int qp = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    rlo = __builtin_amdgcn_update_dpp(lo, lo, qp, 0xf, 0xf, false);
+    rhi = __builtin_amdgcn_update_dpp(hi, hi, qp, 0xf, 0xf, false);
+  }
+  return __hiloint2double(rhi, rlo);
+}
+// src is a compile-time constant after unrolling; the switch folds to one case
+template <class LN>
+__device__ __forceinline__ double tb_team_bcast(LN &ln, int src) {
+  constexpr int WL = LN::WL_;
+  switch (src) {
+#define TB_CASE(i) \
+  case i:          \
+    if constexpr (i < WL) return tb_dpp_bcast<WL, i>(ln.bx); else break;
+    TB_CASE(0) TB_CASE(1) TB_CASE(2) TB_CASE(3) TB_CASE(4) TB_CASE(5) TB_CASE(6) TB_CASE(7)
+    TB_CASE(8) TB_CASE(9) TB_CASE(10) TB_CASE(11) TB_CASE(12) TB_CASE(13) TB_CASE(14) TB_CASE(15)
+#undef TB_CASE
+  }
+  return ln.bx;
+}
+
 // 1/d for the pivot: v_rcp_f64 seed + two Newton steps (full double accuracy for normal d)
 __device__ __forceinline__ double tb_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);

@@ -19,6 +19,9 @@ struct float4 {
 #define TRUSS_UNROLL
 static inline void tb_lds_add(double *p, double v) { *p += v; }
 static inline double tb_rcp(double d) { return 1.0 / d; }
+// DPP row broadcast stand-in: the value lane `src` of this lane's team computed in the previous phase
+template <class LN>
+static inline double tb_team_bcast(LN &ln, int src) { return ln.peers[ln.lane - ln.gs + src].bx; }
 static inline double tb_rsqrt(double x) { return 1.0 / sqrt(x); }
 
 #include "../../mop-truss-marl_amd/csrc/truss_body.h"
@@ -46,7 +49,10 @@ static void emu_run(const truss_topo *t, const StepArgsDev &A) {
   std::vector<Lane> lanes(64);
   for (int b = 0; b < nblocks; ++b) {
     memset(lds.data(), 0xA5, lds.size());  // poison: catches reads of uninitialised LDS
-    for (int l = 0; l < 64; ++l) lanes[l].init(l, b, T, A, lds.data());
+    for (int l = 0; l < 64; ++l) {
+      lanes[l].init(l, b, T, A, lds.data());
+      lanes[l].peers = lanes.data();
+    }
 #define PH(call) \
   for (auto &ln : lanes) ln.call
 #define PH_NS(call) \

@@ -36,7 +36,7 @@ def main():
         env.rollout(G, T, 20)
         torch.cuda.synchronize()
         acc = np.zeros(9)
-        extra = np.zeros(5)
+        extra = np.zeros(9)
         for _ in range(10):
             env.rollout(G, T, 1)
             torch.cuda.synchronize()
@@ -45,7 +45,8 @@ def main():
             s = np.array(list(st)[:10], dtype=np.float64)
             acc += np.diff(s)
             sub = np.array(list(st), dtype=np.float64)
-            extra = extra + np.array([sub[10] - sub[3], sub[11] - sub[10], sub[4] - sub[11], sub[12] - sub[8], sub[9] - sub[12]])
+            extra = extra + np.array([sub[10] - sub[3], sub[11] - sub[10], sub[4] - sub[11], sub[12] - sub[8], sub[9] - sub[12],
+                                      sub[13] - sub[4], sub[5] - sub[13], sub[14] - sub[5], sub[6] - sub[14]])
         acc /= 10
         if len(sys.argv) > 2:
             print(f"{os.path.basename(path):28s} total {acc.sum():7.0f} | " + " ".join(f"{c:6.0f}" for c in acc))
@@ -53,7 +54,8 @@ def main():
         print(f"== {label} B={B}  {topo.solver_info(lib)['lanes_per_env']} lanes/env, total {acc.sum():.0f} cycles")
         for n, c in zip(NAMES, acc):
             print(f"   {n:22s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f} %")
-        for n, c in zip(["elements (pass 1+2)", "assemble_nodes", "scratch_init", "store rows", "finish"], extra / 10):
+        for n, c in zip(["elements (pass 1+2)", "assemble_nodes", "scratch_init", "store rows", "finish",
+                          "factor: clean blocks", "factor: merge blocks + check", "backsub: hand-over blocks", "backsub: clean blocks"], extra / 10):
             print(f"      - {n:20s} {c:9.0f} cyc")
 
 
