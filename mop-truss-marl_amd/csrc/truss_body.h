@@ -145,7 +145,7 @@ struct StepLane {
   static constexpr int NT = G / WL;   // solver teams per env (1, or 2 = two-sided elimination)
 
   int lane, g, gs, team, env, envc;
-  double *Kt, *Zt, *ZRt;  // this lane's team: band rows, {z or P, 1/d} pairs, broadcast ring
+  double *Kt, *Zt, *ZRt;  // this lane's team: band rows, z vector (P_r until row r is eliminated), trash slots
   bool active;
   const char *TB;  // LDS copy of the topology blob
   char *L;         // this env's LDS region
@@ -207,8 +207,8 @@ struct StepLane {
     TB = lds;
     L = lds + T.o_env0 + (size_t)grp * T.env_stride;
     Kt = (double *)(L + T.o_kb) + team * T.rowsA * W;
-    Zt = (double *)(L + T.o_zs) + team * 2 * T.zlen;
-    ZRt = (double *)(L + T.o_zring) + team * 2 * W;
+    Zt = (double *)(L + T.o_zs) + team * T.zlen;     // zlen is even: 16-byte aligned teams
+    ZRt = (double *)(L + T.o_zring) + team * W;    // adjacent banks for the two teams
     bad = 0;
     p_vol = p_dt = p_en = 0.0;
     p_c1 = p_c2 = 0.0f;
@@ -575,7 +575,7 @@ struct StepLane {
     const int lbit = is_roof ? 4 : 2;
     for (int r = g; r < T.zlen * T.nteams; r += G) {   // load vector P in each team's frame (host table)
       const int c = ZC[r];
-      Z[2 * r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
+      Z[r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
     }
     tb_d2 *X2 = (tb_d2 *)__builtin_assume_aligned(xsol(T), 16);
     const tb_d2 z2 = {0.0, 0.0};
@@ -594,21 +594,22 @@ struct StepLane {
       int r = gs + WL * s;
 #pragma unroll
       for (int c = 0; c < W; ++c) R[s][c] = (c <= r) ? Kt[r * W + c] : Kt[c * W + r];  // band rows are stored by column residue
-      rhs[s] = Zt[2 * r];
+      rhs[s] = Zt[r];
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) xs[j] = 0.0;
   }
 
-  // post this lane's entries of pivot column k (kk = k mod W, compile-time after unrolling) and its
-  // right-hand sides; no predication: mirror lanes store the same values to the same addresses
+  // post this lane's entries of pivot column k (kk = k mod W, compile-time after unrolling).  The pivot
+  // lane also publishes its right-hand side z_k: straight into the z vector, where the elimination of
+  // this step and, later, the back substitution find it (slot k held P_k, which the lane took when it
+  // adopted row k).  Nobody wants the other lanes' right-hand sides: their store goes to a per-lane trash
+  // slot (an LDS store costs the same under any exec mask, so the address is selected, not the lanes).
   TRUSS_HD void pivot_write(const TopoDev &T, int k, int kk) {
-    double *ZR = ZRt + (k & 1) * W;
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) {
-      Kt[k * W + gs + WL * s] = R[s][kk];
-      ZR[gs + WL * s] = rhs[s];
-    }
+    for (int s = 0; s < RPL; ++s) Kt[k * W + gs + WL * s] = R[s][kk];
+    double *zp = (gs == kk % WL) ? Zt + k : ZRt + gs;
+    *zp = rhs[kk / WL];
   }
 
   TRUSS_HD void pivot_update(const TopoDev &T, int k, int kk) {
@@ -619,14 +620,9 @@ struct StepLane {
       col[2 * i] = v[0];
       col[2 * i + 1] = v[1];
     }
-    const double zk = ZRt[(k & 1) * W + kk];
+    const double zk = Zt[k];
     const double d = col[kk];
     const double inv = tb_rcp(d);  // d <= 0 / NaN is detected after the loop (pivot_check), off the chain
-    {  // {z_k, 1/d_k} in one 16-byte store (every lane of the team: same values); z_k replaces P_k,
-       // which was consumed when row k entered the window
-      tb_d2 zd = {zk, inv};
-      ((tb_d2 *)__builtin_assume_aligned(Zt, 16))[k] = zd;
-    }
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
       double l = R[s][kk] * inv;
@@ -650,18 +646,18 @@ struct StepLane {
         R[sp][2 * i] = v[0];
         R[sp][2 * i + 1] = v[1];
       }
-      rhs[sp] = Zt[2 * rn];
+      rhs[sp] = Zt[rn];
     }
   }
 
-  // K not SPD <=> some pivot d <= 0 (or NaN): then 1/d is not a positive finite number.  Each lane scans a
-  // share of its team's stored reciprocals once, after the factorisation.  (Team B's idle pivots k >= KA
-  // are not looked at.)
+  // K not SPD <=> some pivot d <= 0 (or NaN / inf).  Each lane scans a share of its team's pivots once,
+  // after the factorisation: d_k sits in the posted column k at residue k mod W.  (Team B's idle pivots
+  // k >= KA are not looked at.)
   TRUSS_HD void pivot_check(const TopoDev &T) {
     const int lim = (T.nteams == 2 && team == 1) ? T.KA : (T.nteams == 2 ? T.KA + W : T.KA);
     for (int k = gs; k < lim; k += WL) {
-      const double v = Zt[2 * k + 1];
-      if (!(v > 0.0) || !(v < 1.7e308)) bad = 1;
+      const double d = Kt[k * W + k % W];
+      if (!(d > 0.0) || !(d < 1.7e308)) bad = 1;
     }
   }
 
@@ -708,7 +704,7 @@ struct StepLane {
   //    broadcast depend on the x_{k+1} the previous step has just produced;
   //  * the rows of the next block are requested while the current block is being solved.
   double bc[RPL][W], bz[RPL], bd[RPL];   // rows owned in the current block
-  double nc[RPL][W], nz[RPL], nd[RPL];   // ... in the next block (in flight)
+  double nc[RPL][W], nz[RPL], nd[RPL];   // ... in the next block (in flight); nd = the pivot d itself
   double bx;                             // this lane's candidate for x_k (valid in the owner lane)
   double myx[RPL] = {};                  // x of the rows this lane owns in the current block
   StepLane *peers = nullptr;             // emulator only: the 64 lanes of the wave (DPP stand-in)
@@ -724,9 +720,8 @@ struct StepLane {
         nc[s][2 * i] = v[0];
         nc[s][2 * i + 1] = v[1];
       }
-      tb_d2 zd = ((const tb_d2 *)__builtin_assume_aligned(Zt, 16))[pc];
-      nz[s] = zd[0];
-      nd[s] = zd[1];
+      nz[s] = Zt[pc];
+      nd[s] = Kt[pc * W + pc % W];   // the pivot d_p (a register array must not be indexed by the lane id)
     }
   }
   TRUSS_HD void backsub_rows_adopt() {
@@ -735,7 +730,8 @@ struct StepLane {
 #pragma unroll
       for (int j = 0; j < W; ++j) bc[s][j] = nc[s][j];
       bz[s] = nz[s];
-      bd[s] = nd[s];
+      // 1/d_p of the owned row: the same operations as in the factorisation, so the same bits; once per block and lane
+      bd[s] = tb_rcp(nd[s]);
     }
   }
   TRUSS_HD void backsub_step(const TopoDev &T, int k, int kk) {

@@ -492,11 +492,11 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   // the back substitution `red` (objective partials) reuses the z vectors
   {
     size_t o0 = off;
-    D.o_zs = carve(sizeof(double) * 2 * (size_t)zlen * nteams);  // {z or P, 1/d} pairs
+    D.o_zs = carve(sizeof(double) * (size_t)zlen * nteams);  // z vector per team (zlen is even)
     D.o_dinv = D.o_zs;
     D.o_xsol = carve(sizeof(double) * (zslot + 4));  // + zero slot, dummy slot, 16-byte fill
     D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
-    D.o_zring = carve(sizeof(double) * 2 * W * nteams);
+    D.o_zring = carve(sizeof(double) * W * nteams);   // per-lane trash slots
     D.o_ev = (int32_t)o0;
     size_t need = sizeof(double) * 3 * ((size_t)E + 1);
     if (off - o0 < need) off = (o0 + need + 15) & ~size_t(15);
