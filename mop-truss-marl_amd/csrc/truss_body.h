@@ -614,6 +614,11 @@ struct StepLane {
 
   TRUSS_HD void pivot_update(const TopoDev &T, int k, int kk) {
     double col[W];
+    {  // this lane's entries of the entering column k+W: static data, requested before the posted column
+      const double *Kn = Kt + (k + W) * W;
+#pragma unroll
+      for (int s = 0; s < RPL; ++s) ecol[s] = Kn[gs + WL * s];
+    }
 #pragma unroll
     for (int i = 0; i < W / 2; ++i) {
       tb_d2 v = ((const tb_d2 *)__builtin_assume_aligned(Kt + k * W, 16))[i];
@@ -631,22 +636,36 @@ struct StepLane {
         if (j != kk) R[s][j] = fma(-l, col[j], R[s][j]);
       rhs[s] = fma(-l, zk, rhs[s]);
     }
-    // the window slides: column k leaves, column k+W enters; the pivot row's lane adopts row k+W.
-    // Band rows are stored by column residue (entry (r, c) at r*W + c%W), so a row loads straight into
-    // the window registers and every other lane finds its entry of the new column at its own residue.
-    const int rn = k + W;
-    const double *Kn = Kt + rn * W;
+    // the window slides: column k leaves, column k+W enters; the pivot row's lane adopts row k+W, which
+    // it requested at the start of this block of W pivots (factor_rows_fetch).  Band rows are stored by
+    // column residue (entry (r, c) at r*W + c%W): a row maps straight onto the window registers and every
+    // other lane finds its entry of the new column at its own residue.
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) R[s][kk] = Kn[gs + WL * s];
+    for (int s = 0; s < RPL; ++s) R[s][kk] = ecol[s];
     if (gs == kk % WL) {
       const int sp = kk / WL;
 #pragma unroll
+      for (int j = 0; j < W; ++j) R[sp][j] = fr[sp][j];
+      rhs[sp] = frhs[sp];
+    }
+  }
+  // Rows kb+W .. kb+2W-1 enter the window during the W pivots of block kb, one per pivot, each into the
+  // lane that owned the eliminated row.  They are static in the LDS until then, so every lane fetches its
+  // successor rows once per block (4 reads per block and lane instead of 4 per pivot and wave, and their
+  // latency is off the pivot chain).
+  double fr[RPL][W], frhs[RPL], ecol[RPL];
+  TRUSS_HD void factor_rows_fetch(const TopoDev &T, int kb) {
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+      const int rn = kb + W + gs + WL * s;
+      const tb_d2 *K2 = (const tb_d2 *)__builtin_assume_aligned(Kt + rn * W, 16);
+#pragma unroll
       for (int i = 0; i < W / 2; ++i) {
-        tb_d2 v = ((const tb_d2 *)__builtin_assume_aligned(Kn, 16))[i];
-        R[sp][2 * i] = v[0];
-        R[sp][2 * i + 1] = v[1];
+        tb_d2 v = K2[i];
+        fr[s][2 * i] = v[0];
+        fr[s][2 * i + 1] = v[1];
       }
-      rhs[sp] = Zt[rn];
+      frhs[s] = Zt[rn];
     }
   }
 
@@ -1026,6 +1045,7 @@ struct StepLane {
     const int kend_ = (T).nteams == 2 ? (T).KA + W_ : (T).KA;                       \
     int kb_ = 0;                                                                    \
     for (; kb_ + W_ <= (T).KA; kb_ += W_) {                                         \
+      PH_NS(factor_rows_fetch(T, kb_));                                             \
       TRUSS_UNROLL                                                                  \
       for (int kk_ = 0; kk_ < W_; ++kk_) {                                          \
         PH(pivot_write(T, kb_ + kk_, kk_));                                         \
@@ -1034,6 +1054,7 @@ struct StepLane {
     }                                                                               \
     TRUSS_ST(13);                                                                   \
     for (; kb_ < kend_; kb_ += W_) {                                                \
+      PH_NS(factor_rows_fetch(T, kb_));                                             \
       TRUSS_UNROLL                                                                  \
       for (int kk_ = 0; kk_ < W_; ++kk_) {                                          \
         if (kb_ + kk_ < kend_) {                                                    \

@@ -69,10 +69,17 @@ __device__ __forceinline__ double tb_rcp(double d) {
 // Diagnostic build only (make diag): lane 0 of one mid-grid workgroup records s_memtime at the phase
 // boundaries into a buffer nothing else reads.  Never enabled in libtruss_mi355.so.
 __device__ unsigned long long g_truss_stamps[16];
+// g_truss_span: every workgroup's first and last stamp as (shader clock, 100 MHz wall clock): spread of
+// the workgroups over the launch, effective shader frequency (tools/span.py).
+__device__ unsigned long long g_truss_span[4096][4];
 #define TRUSS_ST(i)                                                  \
   do {                                                               \
     __builtin_amdgcn_sched_barrier(0);                               \
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_truss_stamps[i] = clock64(); \
+    if (threadIdx.x == 0 && ((i) == 0 || (i) == 9) && blockIdx.x < 4096) {              \
+      g_truss_span[blockIdx.x][(i) == 0 ? 0 : 2] = clock64();                            \
+      g_truss_span[blockIdx.x][(i) == 0 ? 1 : 3] = wall_clock64();                       \
+    }                                                                \
     __builtin_amdgcn_sched_barrier(0);                               \
   } while (0)
 #endif
@@ -187,6 +194,9 @@ static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *strea
 }
 
 #ifdef TRUSS_STAMPS
+extern "C" int truss_debug_span(unsigned long long *out, int nblocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_truss_span), (size_t)nblocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
 extern "C" int truss_debug_stamps(unsigned long long *out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_truss_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }

@@ -48,10 +48,14 @@ def main():
             extra = extra + np.array([sub[10] - sub[3], sub[11] - sub[10], sub[4] - sub[11], sub[12] - sub[8], sub[9] - sub[12],
                                       sub[13] - sub[4], sub[5] - sub[13], sub[14] - sub[5], sub[6] - sub[14]])
         acc /= 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); env.rollout(G, T, 200); e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 200
         if len(sys.argv) > 2:
-            print(f"{os.path.basename(path):28s} total {acc.sum():7.0f} | " + " ".join(f"{c:6.0f}" for c in acc))
+            print(f"{os.path.basename(path):28s} total {acc.sum():7.0f} cyc, launch {us:6.2f} us -> {acc.sum() / us / 1e3:4.2f} GHz if the "
+                  f"workgroup spanned the launch | " + " ".join(f"{c:6.0f}" for c in acc))
             continue
-        print(f"== {label} B={B}  {topo.solver_info(lib)['lanes_per_env']} lanes/env, total {acc.sum():.0f} cycles")
+        print(f"== {label} B={B}  {topo.solver_info(lib)['lanes_per_env']} lanes/env, total {acc.sum():.0f} cycles; stamped launch {us:.2f} us")
         for n, c in zip(NAMES, acc):
             print(f"   {n:22s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f} %")
         for n, c in zip(["elements (pass 1+2)", "assemble_nodes", "scratch_init", "store rows", "finish",
