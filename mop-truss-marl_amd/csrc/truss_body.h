@@ -1040,8 +1040,8 @@ struct StepLane {
   TRUSS_ST(4);                                                                      \
   PH(solver_init(T));                                                               \
   {                                                                                 \
-    /* Factorisation.  Blocks of W pivots that lie entirely inside a team's own part run the clean,  \
-       unguarded body; only the (at most two) blocks around the merge point carry guards. */         \
+    /* Factorisation.  Blocks of W pivots that lie entirely inside a team's own part run the clean   \
+       block loop. */                                                                                \
     const int kend_ = (T).nteams == 2 ? (T).KA + W_ : (T).KA;                       \
     int kb_ = 0;                                                                    \
     for (; kb_ + W_ <= (T).KA; kb_ += W_) {                                         \
@@ -1053,43 +1053,102 @@ struct StepLane {
       }                                                                             \
     }                                                                               \
     TRUSS_ST(13);                                                                   \
-    for (; kb_ < kend_; kb_ += W_) {                                                \
-      PH_NS(factor_rows_fetch(T, kb_));                                             \
+    /* Two-sided scheme: the rest of team A's/B's own pivots of this block, the merge at k = KA, and the \
+       W pivots of the middle block.  Where the merge falls inside a block of W (c = KA mod W) is a      \
+       property of the topology; the region is instantiated for every c and one instance runs, so that   \
+       all window indices are compile-time and no pivot carries a guard. */                              \
+    if ((T).nteams == 2 && W_ <= 8) {                                               \
+      const int c0_ = (T).KA % W_;                                                  \
       TRUSS_UNROLL                                                                  \
-      for (int kk_ = 0; kk_ < W_; ++kk_) {                                          \
-        if (kb_ + kk_ < kend_) {                                                    \
-          if (kb_ + kk_ == (T).KA) {                                                \
-            PH(merge_post(T));                                                      \
-            PH(merge_take(T));                                                      \
+      for (int c_ = 0; c_ < W_; ++c_) {                                             \
+        if (c_ == c0_) {                                                            \
+          if (c_ > 0) { PH_NS(factor_rows_fetch(T, kb_)); }                         \
+          TRUSS_UNROLL                                                              \
+          for (int kk_ = 0; kk_ < c_; ++kk_) {                                      \
+            PH(pivot_write(T, kb_ + kk_, kk_));                                     \
+            PH_NS(pivot_update(T, kb_ + kk_, kk_));                                 \
           }                                                                         \
-          PH(pivot_write(T, kb_ + kk_, kk_));                                       \
-          PH_NS(pivot_update(T, kb_ + kk_, kk_));                                   \
+          PH(merge_post(T));                                                        \
+          PH(merge_take(T));                                                        \
+          TRUSS_UNROLL                                                              \
+          for (int i_ = 0; i_ < W_; ++i_) {                                         \
+            if ((c_ + i_) % W_ == 0) { PH_NS(factor_rows_fetch(T, (T).KA + i_)); }  \
+            PH(pivot_write(T, (T).KA + i_, (c_ + i_) % W_));                        \
+            PH_NS(pivot_update(T, (T).KA + i_, (c_ + i_) % W_));                    \
+          }                                                                         \
+        }                                                                           \
+      }                                                                             \
+    } else if ((T).nteams == 2) { /* wide windows: W instances would not fit; guarded blocks instead */ \
+      for (; kb_ < kend_; kb_ += W_) {                                              \
+        PH_NS(factor_rows_fetch(T, kb_));                                           \
+        TRUSS_UNROLL                                                                \
+        for (int kk_ = 0; kk_ < W_; ++kk_) {                                        \
+          if (kb_ + kk_ < kend_) {                                                  \
+            if (kb_ + kk_ == (T).KA) {                                              \
+              PH(merge_post(T));                                                    \
+              PH(merge_take(T));                                                    \
+            }                                                                       \
+            PH(pivot_write(T, kb_ + kk_, kk_));                                     \
+            PH_NS(pivot_update(T, kb_ + kk_, kk_));                                 \
+          }                                                                         \
         }                                                                           \
       }                                                                             \
     }                                                                               \
     BAR();                                                                          \
     PH_NS(pivot_check(T));                                                          \
     TRUSS_ST(5);                                                                    \
-    /* Back substitution, top block first.  Special (guarded) blocks: those that contain the first step \
-       kend-1 or the hand-over step KA-1 of the two-sided scheme; everything below runs clean. */    \
+    /* Back substitution, top row first.  Two-sided scheme: the W steps of the middle block, the hand-over \
+       of the middle solutions to team B at k = KA - 1 and the rest of that block, instantiated per        \
+       c = KA mod W like the merge region above; everything below runs the clean block loop. */            \
     kb_ = ((kend_ - 1) / W_) * W_;                                                  \
     PH_NS(backsub_rows_fetch(T, kb_));                                              \
-    for (; (T).nteams == 2 && kb_ >= 0 && kb_ + W_ - 1 >= (T).KA - 1; kb_ -= W_) {  \
-      PH_NS(backsub_rows_adopt());                                                  \
-      PH_NS(backsub_rows_fetch(T, kb_ - W_));                                       \
+    if ((T).nteams == 2 && W_ <= 8) {                                               \
+      const int c0_ = (T).KA % W_;                                                  \
       TRUSS_UNROLL                                                                  \
-      for (int kk_ = W_ - 1; kk_ >= 0; --kk_) {                                     \
-        if (kb_ + kk_ < kend_) {                                                    \
-          if (kb_ + kk_ == (T).KA - 1) {                                            \
-            PH_NS(backsub_flush_mid(T));                                            \
-            BAR();                                                                  \
-            PH_NS(backsub_reload(T));                                               \
+      for (int c_ = 0; c_ < W_; ++c_) {                                             \
+        if (c_ == c0_) {                                                            \
+          PH_NS(backsub_rows_adopt());                                              \
+          PH_NS(backsub_rows_fetch(T, kb_ - W_));                                   \
+          TRUSS_UNROLL                                                              \
+          for (int i_ = W_ - 1; i_ >= 0; --i_) {                                    \
+            PH_NS(backsub_step(T, (T).KA + i_, (c_ + i_) % W_));                    \
+            PH_NS(backsub_share((c_ + i_) % W_));                                   \
+            if ((c_ + i_) % W_ == 0 && i_ > 0) { /* into the block below */        \
+              kb_ -= W_;                                                            \
+              PH_NS(backsub_rows_adopt());                                          \
+              PH_NS(backsub_rows_fetch(T, kb_ - W_));                               \
+            }                                                                       \
           }                                                                         \
-          PH_NS(backsub_step(T, kb_ + kk_, kk_));                                   \
-          PH_NS(backsub_share(kk_));                                                \
+          PH_NS(backsub_flush_mid(T));                                              \
+          BAR();                                                                    \
+          PH_NS(backsub_reload(T));                                                 \
+          TRUSS_UNROLL                                                              \
+          for (int kk_ = c_ - 1; kk_ >= 0; --kk_) {                                 \
+            PH_NS(backsub_step(T, kb_ + kk_, kk_));                                 \
+            PH_NS(backsub_share(kk_));                                              \
+          }                                                                         \
+          if (c_ > 0) { PH_NS(backsub_flush(T, kb_)); }                             \
+          kb_ -= W_;                                                                \
         }                                                                           \
       }                                                                             \
-      PH_NS(backsub_flush(T, kb_));                                                 \
+    } else if ((T).nteams == 2) {                                                   \
+      for (; kb_ >= 0 && kb_ + W_ - 1 >= (T).KA - 1; kb_ -= W_) {                   \
+        PH_NS(backsub_rows_adopt());                                                \
+        PH_NS(backsub_rows_fetch(T, kb_ - W_));                                     \
+        TRUSS_UNROLL                                                                \
+        for (int kk_ = W_ - 1; kk_ >= 0; --kk_) {                                   \
+          if (kb_ + kk_ < kend_) {                                                  \
+            if (kb_ + kk_ == (T).KA - 1) {                                          \
+              PH_NS(backsub_flush_mid(T));                                          \
+              BAR();                                                                \
+              PH_NS(backsub_reload(T));                                             \
+            }                                                                       \
+            PH_NS(backsub_step(T, kb_ + kk_, kk_));                                 \
+            PH_NS(backsub_share(kk_));                                              \
+          }                                                                         \
+        }                                                                           \
+        PH_NS(backsub_flush(T, kb_));                                               \
+      }                                                                             \
     }                                                                               \
     TRUSS_ST(14);                                                                   \
     for (; kb_ >= 0; kb_ -= W_) {                                                   \
