@@ -248,18 +248,27 @@ struct StepLane {
     }                                  // branch, so the compiler cannot sink the load under a guard
   }
 
-  TRUSS_HD void phase_stage(const TopoDev &T, const StepArgsDev &A) {
+  // clear the band with 16-byte stores (padding-row identity is written after the next barrier).  The
+  // band geometry comes with the kernel arguments, not with the blob being staged.
+  TRUSS_HD void band_clear(const TopoDev &T) {
+    tb_u4 *K4 = (tb_u4 *)kb(T);
+    const tb_u4 z = {0u, 0u, 0u, 0u};
+    const int tot4 = ((T.rowsA + T.rowsB) * W) >> 1;
+    for (int i = g; i < tot4; i += G) K4[i] = z;
+  }
+
+  // BI = 16-byte blob units per lane (unrolled): every iteration is a global load and an LDS store for the
+  // whole wave whether or not the blob reaches that far, so the common small blob gets its own instance
+  template <int BI>
+  TRUSS_HD void stage_fast(const TopoDev &T, const StepArgsDev &A, bool decode) {
     const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
-    const bool decode = !(A.flags & TB_NO_DECODE);
-    const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= 64 && T.E <= 128 && T.blob_bytes <= BIT * 64 * 16;
-    heads = A.coin ? (A.coin[envc] != 0) : 0;
-    if (fast) {
+    {
       const int nb = T.blob_bytes >> 4, nn = T.N >> 2, ne = T.E >> 2;
-      tb_u4 vb[BIT], vy[NIT], vx[NIT], vt[NIT], vs[EIT], vp[1], vg[2 * NIT], va[3 * NIT];
+      tb_u4 vb[BI], vy[NIT], vx[NIT], vt[NIT], vs[EIT], vp[1], vg[2 * NIT], va[3 * NIT];
       {
         const tb_u4 *s4 = (const tb_u4 *)T.blob;
 #pragma unroll
-        for (int i = 0; i < BIT; ++i) {
+        for (int i = 0; i < BI; ++i) {
           int q = lane + 64 * i;
           vb[i] = s4[q < nb ? q : nb - 1];
         }
@@ -273,10 +282,11 @@ struct StepLane {
         row_load<2 * NIT>(A.a_geo + bn * 2, 2 * nn, vg);
         row_load<3 * NIT>(A.a_topo + bn * 3, 3 * nn, va);
       }
+      band_clear(T);   // independent of the loads in flight: its LDS stores overlap the HBM latency
       {
         tb_u4 *d4 = (tb_u4 *)TB;
 #pragma unroll
-        for (int i = 0; i < BIT; ++i) {
+        for (int i = 0; i < BI; ++i) {
           int q = lane + 64 * i;
           d4[q < nb ? q : nb - 1] = vb[i];
         }
@@ -290,6 +300,17 @@ struct StepLane {
         row_store<2 * NIT>(geosh(T), 2 * nn, vg);
         row_store<3 * NIT>(tac(T), 3 * nn, va);
       }
+    }
+  }
+
+  TRUSS_HD void phase_stage(const TopoDev &T, const StepArgsDev &A) {
+    const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
+    const bool decode = !(A.flags & TB_NO_DECODE);
+    const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= 64 && T.E <= 128 && T.blob_bytes <= BIT * 64 * 16;
+    heads = A.coin ? (A.coin[envc] != 0) : 0;
+    if (fast) {
+      if (T.blob_bytes <= 3 * 64 * 16) stage_fast<3>(T, A, decode);
+      else stage_fast<BIT>(T, A, decode);
     } else {
       {
         const tb_u4 *s4 = (const tb_u4 *)T.blob;
@@ -305,13 +326,7 @@ struct StepLane {
         stage_row_slow(A.a_geo + bn * 2, geosh(T), 2 * T.N);
         stage_row_slow(A.a_topo + bn * 3, tac(T), 3 * T.N);
       }
-    }
-    // clear the band with 16-byte stores (padding-row identity is written after the next barrier)
-    {
-      tb_u4 *K4 = (tb_u4 *)kb(T);
-      const tb_u4 z = {0u, 0u, 0u, 0u};
-      const int tot4 = ((T.rowsA + T.rowsB) * W) >> 1;
-      for (int i = g; i < tot4; i += G) K4[i] = z;
+      band_clear(T);
     }
   }
 
