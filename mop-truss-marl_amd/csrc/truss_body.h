@@ -940,7 +940,7 @@ struct StepLane {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       int q = g + G * i;
-      d4[q < nq ? q : nq - 1] = v[i];  // clamped duplicates rewrite the same 16 bytes
+      TB_STREAM_STORE(&d4[q < nq ? q : nq - 1], v[i]);  // clamped duplicates rewrite the same 16 bytes
     }
   }
 
@@ -1329,7 +1329,7 @@ struct ObsLane {
       const float *lo = mn(T), *hi = mx(T);
       for (int i = lane; i < T.N * 13; i += 64) {
         int c = i % 13;
-        o[i] = (R[i] - lo[c]) / (hi[c] - lo[c] + 1e-6f);
+        TB_STREAM_STORE(&o[i], (R[i] - lo[c]) / (hi[c] - lo[c] + 1e-6f));
       }
     }
     const int nn = T.N * T.N;
@@ -1341,9 +1341,9 @@ struct ObsLane {
       float *o = outs[m] + (size_t)env * nn;
       const float *src = M + m * nn;
       if ((nn & 3) == 0) {
-        const float4 *s4 = (const float4 *)src;
-        float4 *o4 = (float4 *)o;
-        for (int i = lane; i < nn / 4; i += 64) o4[i] = s4[i];
+        const tb_u4 *s4 = (const tb_u4 *)src;
+        tb_u4 *o4 = (tb_u4 *)o;
+        for (int i = lane; i < nn / 4; i += 64) TB_STREAM_STORE(&o4[i], s4[i]);
       } else {
         for (int i = lane; i < nn; i += 64) o[i] = src[i];
       }

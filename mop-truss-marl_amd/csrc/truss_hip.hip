@@ -15,6 +15,9 @@
 #define TRUSS_HD __device__ __forceinline__
 #define TRUSS_UNROLL _Pragma("unroll")
 #define TB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// result rows are written once and not read again by this launch: streaming (non-temporal) stores leave
+// no dirty lines behind for the end-of-kernel write-back
+#define TB_STREAM_STORE(p, v) __builtin_nontemporal_store((v), (p))
 
 // LDS float64 scatter-add (ds_add_f64 on gfx950)
 __device__ __forceinline__ void tb_lds_add(double *p, double v) { unsafeAtomicAdd(p, v); }

@@ -17,6 +17,7 @@ struct float4 {
 };
 #define TRUSS_HD inline
 #define TRUSS_UNROLL
+#define TB_STREAM_STORE(p, v) (*(p) = (v))
 static inline void tb_lds_add(double *p, double v) { *p += v; }
 static inline double tb_rcp(double d) { return 1.0 / d; }
 // DPP row broadcast stand-in: the value lane `src` of this lane's team computed in the previous phase
