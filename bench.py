@@ -137,6 +137,34 @@ def main():
         obs_bytes = 4 * (13 * topo.N + 3 * topo.N ** 2 + 12 * topo.N + 21 * topo.E)
         extras["obs_kernel_us"] = obs_us
         extras["obs_GBps"] = B * obs_bytes / (obs_us * 1e-6) / 1e9
+        # state-emitting step (configs 3-5): env.step + env.observe per step, against SURVEY §8d B_obs
+        # (the reference's 5 N^2 matrices; A_n and mask are topology-static here and are not re-written)
+        ag0, at0 = G[0].contiguous(), T[0].contiguous()
+        env.step(ag0, at0); env.observe(); torch.cuda.synchronize()
+        a0.record()
+        for _ in range(100):
+            env.step(ag0, at0)
+            env.observe()
+        a1.record(); torch.cuda.synchronize()
+        so_us = a0.elapsed_time(a1) * 1e3 / 100
+        b_obs = algorithmic_bytes_per_env_step(topo.N, topo.E) + 4 * (13 * topo.N + 5 * topo.N ** 2 + 12 * topo.N + 21 * topo.E)
+        extras["step_plus_obs_us"] = so_us
+        extras["step_plus_obs_env_steps_per_s"] = B / (so_us * 1e-6)
+        extras["step_plus_obs_frac_of_hbm_peak_B_obs"] = B * b_obs / (so_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        # BASELINE configs[1] topology: small bridge, 16 nodes / 36 elements (reference-exact grid)
+        t36 = tm.TrussTopology.grid(8)
+        b36 = synthetic.random_batch(t36, B, seed=7)
+        e36 = tm.BatchedTruss(t36, B, device=dev, lib=lib)
+        e36.set_constants(b36["x"], b36["target"], b36["y_max"], b36["d_min"], b36["max_def"], b36["load_x"],
+                          b36["load_y"], b36["is_roof"])
+        e36.set_design(b36["y"], b36["sec"])
+        e36.analyze(set_normalisers=True)
+        g36, a36 = synthetic.random_actions(N_ACTION_SETS, B, t36.N, 5)
+        g36, a36 = torch.tensor(g36, device=dev), torch.tensor(a36, device=dev)
+        e36.rollout(g36, a36, args.warmup); torch.cuda.synchronize()
+        a0.record(); e36.rollout(g36, a36, args.steps); a1.record(); torch.cuda.synchronize()
+        extras["small_bridge_16n36e_env_steps_per_s"] = B * args.steps / (a0.elapsed_time(a1) * 1e-3)
+        extras["small_bridge_lanes_per_env"] = t36.solver_info(lib)["lanes_per_env"]
 
     if rank == 0:
         per_step_bytes = algorithmic_bytes_per_env_step(topo.N, topo.E) * B
@@ -172,6 +200,8 @@ def main():
                 "traffic": 13389312 if (B == 4096 and topo.N == 32 and topo.E == 80) else None,
                 "kernel": "truss_step_kernel", "kernel_us": kern_s * 1e6,
                 "bytes_per_launch": per_step_bytes,
+                # the other two ceilings SURVEY §8d asks for (algorithmic banded flop count, 1e4 per env-step)
+                "fp64_gflops": 1.0e4 * B / kern_s / 1e9, "fp64_frac_of_78.6_TFLOPs": 1.0e4 * B / kern_s / 78.6e12,
             },
             "nonpositive_pivots": st,
         }

@@ -72,6 +72,8 @@ class BatchedTruss:
         self.disp_f64 = z((B, N, 2), f64) if debug_f64 else None
         self.q0_f64 = z((B, E), f64) if debug_f64 else None
         self._coin0 = z((B,), u8)
+        self._step_cache = {}
+        self._obs_cache = {}
 
     # current design
     @property
@@ -149,18 +151,29 @@ class BatchedTruss:
         """One `_game_modify` per env from the current design; the new design becomes current.
         a_geo [B,N,2], a_topo [B,N,3] float32 on the env's device."""
         B, N = self.B, self.N
-        self._chk(a_geo, (B, N, 2), torch.float32, "a_geo")
-        self._chk(a_topo, (B, N, 3), torch.float32, "a_topo")
-        self._chk(coin, (B,), torch.uint8, "coin")
-        self._chk(max_up_in, (B, N), torch.float32, "max_up_in")
-        self._chk(max_down_in, (B, N), torch.float32, "max_down_in")
         if coin is None:
             coin = self._coin0
         nxt = self.cur ^ 1
         flags = _lib.F_CLAMP_INPLACE if clamp_inplace else 0
-        a = self._args(flags, a_geo, a_topo, coin, max_up_in, max_down_in, self.ybuf[self.cur], self.secbuf[self.cur],
-                       self.ybuf[nxt], self.secbuf[nxt])
-        self.lib.check(self.lib.dll.truss_step(self.h, C.byref(a), self._stream()), "truss_step")
+        # an RL loop passes the same buffers every step: validated argument blocks are kept per buffer set
+        key = (self.cur, flags, a_geo.data_ptr(), a_topo.data_ptr(), coin.data_ptr(),
+               0 if max_up_in is None else max_up_in.data_ptr(), 0 if max_down_in is None else max_down_in.data_ptr(),
+               a_geo.shape, a_topo.shape)
+        a = self._step_cache.get(key)
+        if a is None:
+            self._chk(a_geo, (B, N, 2), torch.float32, "a_geo")
+            self._chk(a_topo, (B, N, 3), torch.float32, "a_topo")
+            self._chk(coin, (B,), torch.uint8, "coin")
+            self._chk(max_up_in, (B, N), torch.float32, "max_up_in")
+            self._chk(max_down_in, (B, N), torch.float32, "max_down_in")
+            a = self._args(flags, a_geo, a_topo, coin, max_up_in, max_down_in, self.ybuf[self.cur], self.secbuf[self.cur],
+                           self.ybuf[nxt], self.secbuf[nxt])
+            if len(self._step_cache) > 64:
+                self._step_cache.clear()
+            self._step_cache[key] = a
+        rc = self.lib.dll.truss_step(self.h, C.byref(a), self._stream())
+        if rc:
+            self.lib.check(rc, "truss_step")
         self.cur = nxt
 
     def rollout(self, a_geo_sets, a_topo_sets, n_steps, coin=None):
@@ -192,6 +205,14 @@ class BatchedTruss:
                 self._obs = dict(x_n=mk(B, N, 13), A_s=mk(B, N, N), A_n_ts=mk(B, N, N), A_n_cs=mk(B, N, N),
                                  nN_x_n=mk(B, N, 12), nN_x_e=mk(B, E, 21))
             out = self._obs
+        key = (self.cur, id(out)) + tuple(0 if out.get(k) is None else out[k].data_ptr()
+                                          for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e"))
+        a = self._obs_cache.get(key)
+        if a is not None:
+            rc = self.lib.dll.truss_obs(self.h, C.byref(a), self._stream())
+            if rc:
+                self.lib.check(rc, "truss_obs")
+            return out
         a = _lib.ObsArgs()
         a.struct_size = C.sizeof(_lib.ObsArgs)
         a.n_envs, a.flags = B, 0
@@ -201,6 +222,9 @@ class BatchedTruss:
         a.env_params = _ptr(self.env_params)
         a.x_n, a.A_s, a.A_n_ts, a.A_n_cs = _ptr(out.get("x_n")), _ptr(out.get("A_s")), _ptr(out.get("A_n_ts")), _ptr(out.get("A_n_cs"))
         a.nN_x_n, a.nN_x_e = _ptr(out.get("nN_x_n")), _ptr(out.get("nN_x_e"))
+        if len(self._obs_cache) > 16:
+            self._obs_cache.clear()
+        self._obs_cache[key] = a
         self.lib.check(self.lib.dll.truss_obs(self.h, C.byref(a), self._stream()), "truss_obs")
         return out
 
@@ -214,3 +238,4 @@ class BatchedTruss:
             out["disp_f64"] = g(self.disp_f64)
             out["q0_f64"] = g(self.q0_f64)
         return out
+
