@@ -8,3 +8,4 @@ master_DDPG_truss2D_MO) live one directory up and are built on these two classes
 from ._lib import TrussError, load, F_NO_DECODE, F_CLAMP_INPLACE  # noqa: F401
 from .topology import TrussTopology, SECTION_TABLE_CM, sections_si, YOUNG_MODULUS, LONG_STRESS  # noqa: F401
 from .batched import BatchedTruss  # noqa: F401
+from . import genes  # noqa: F401
