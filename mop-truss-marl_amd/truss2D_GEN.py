@@ -95,13 +95,54 @@ class gen_model:
         self.n_u_coord = [[x, y] for y in self.n_u_y for x in self.n_u_x]
 
     def savetxt(self, name):
-        with open(name, "w+") as f:
+        """Structure dump (truss2D_GEN.py:193-211): loads, nodes, elements, one literal per CRLF-ended line.
+        Written in numpy 1.x's scalar print mode (the reference pins numpy 1.23.5): under numpy 2.x a
+        numpy scalar inside a list prints as `np.float64(..)`, which `read_src` (ast.literal_eval) rejects."""
+        import numpy as _np
+        try:
+            ctx = _np.printoptions(legacy="1.25")
+        except (TypeError, ValueError):          # numpy 1.x: already prints plain literals
+            import contextlib as _cl
+            ctx = _cl.nullcontext()
+        with ctx, open(name, "w+") as f:
             for l in self.model.loads:
                 f.write(" {}\r\n".format(l))
             for n in self.model.nodes:
                 f.write(" {}\r\n".format(n))
             for e in self.model.elements:
                 f.write(" {},{},{},{},{},{}\r\n".format(e.name, e.nodes[0].name, e.nodes[1].name, e.em, e.area, e.i))
+
+    def read_src(self, src):
+        """Load a structure dump written by `savetxt` back into the model (the reader the reference ships
+        with its render scripts, test/*/render/truss2D_READ.py:136-172): one literal per line; 2 items =
+        load (name, [Fx, Fy]), 4 = node (name, [x, y], [rx, ry], loads), 6 = element (name, n0, n1, E, A,
+        [[I]]); the section number is recovered by matching the area against the section table."""
+        import ast
+        for line in open(src):
+            text = line.rstrip("\r\n").replace(" ", "")
+            if not text:
+                continue
+            val = ast.literal_eval(text)
+            if len(val) == 2:
+                for l in self.model.loads:
+                    if l.name == val[0]:
+                        l.size[0], l.size[1] = val[1][0], val[1][1]
+            elif len(val) == 4:
+                for n in self.model.nodes:
+                    if n.name == val[0]:
+                        n.coord[0], n.coord[1] = val[1][0], val[1][1]
+                        n.res[0], n.res[1] = val[2][0], val[2][1]
+            elif len(val) == 6:
+                for e in self.model.elements:
+                    if e.name == val[0]:
+                        e.em, e.area = val[3], val[4]
+                        e.i[0][0] = val[5][0][0]
+                        for k in range(len(self.truss)):
+                            if e.area == self.truss[k][0] * 1e-4:
+                                e.section_no = k
+            else:
+                print('ERROR')
+                break
 
     def _element(self, name, a, b):
         e = Element()

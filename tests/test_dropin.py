@@ -137,3 +137,36 @@ def test_dropin_utils_match_reference_answers():
         np.testing.assert_allclose([len(front), max_d, dis_d, p_cd, sum_d, float(std_cd)], sc, rtol=1e-12, atol=1e-12)
     out7 = utils.simple_cull([[0.5, 0.5, 0, 0, 0], [0.4, 0.6, 0, 0, 1]], True)
     assert len(out7) == 7 and out7[6] is out7[0]
+
+
+def test_structure_dump_format_round_trip(tmp_path):
+    """Row f-3: `gen_model.savetxt` writes, byte for byte, what the reference writes for the same design
+    (fixture = a dump produced by the reference's own savetxt, tests/golden/make_golden_formats.py), and
+    `read_src` (the reader of the reference's render scripts) loads it back."""
+    import json
+    import FEM_2Dtruss
+    import truss2D_GEN
+    FEM_2Dtruss._LIB = pc.emu_lib()
+    try:
+        want = json.load(open(os.path.join(GOLDEN, "structure_small_bridge.json")))
+        ref_txt = open(os.path.join(GOLDEN, "structure_small_bridge.txt"), newline="").read()
+        with contextlib.redirect_stdout(io.StringIO()):
+            gm = truss2D_GEN.gen_model(*want["args"])
+            fresh = truss2D_GEN.gen_model(*want["args"])
+        # reader: the reference's dump -> model
+        fresh.read_src(os.path.join(GOLDEN, "structure_small_bridge.txt"))
+        assert [n.coord[1] for n in fresh.model.nodes] == want["y"]
+        assert [e.section_no for e in fresh.model.elements] == want["sec"]
+        # writer: the same design set by hand -> identical bytes (CRLF line ends included)
+        for n, y in zip(gm.model.nodes, want["y"]):
+            if n.top_node == 1:              # untouched coordinates keep the builder's (integer) literals
+                n.coord[1] = y
+        for e, s in zip(gm.model.elements, want["sec"]):
+            e.section_no = s
+            e.area = gm.truss[s][0] * 1e-4
+            e.set_i(gm.truss[s][1] * 1e-8)
+        out = tmp_path / "dump.txt"
+        gm.savetxt(str(out))
+        assert open(out, newline="").read() == ref_txt
+    finally:
+        FEM_2Dtruss._LIB = None
