@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TRUSS_ABI_VERSION 1
+#define TRUSS_ABI_VERSION 2
 
 #define TRUSS_OK 0
 #define TRUSS_EINVAL (-1)       /* bad argument (NULL, size mismatch, pair table not an involution ...) */
@@ -185,6 +185,46 @@ typedef struct truss_obs_args {
 } truss_obs_args_t;
 
 int truss_obs(const truss_topo_t *t, const truss_obs_args_t *args, void *stream);
+
+/* ---- Pareto front + hypervolume of a batch of small point sets --------------------------------
+ * replaces: utils.simple_cull / simple_cull_final (train copy utils.py:11-217, test copies :220-403) and
+ * utils.union_rectangles_fastest (:275-342), which the reward block of master_DDPG_truss2D_MO.run()
+ * (:263-368) calls 5 + 6 times per archived solution, for B envs at once.
+ *
+ * Per env: n_points[b] rows [obj1, obj2, con1, con2] (n <= max_points <= 64).
+ *   feasible  = not (con1 > 1 or con2 > 1)                                   (utils.py:18-22)
+ *   front     = feasible rows no other feasible row beats in BOTH objectives (strict), identical rows once,
+ *               sorted by obj1 (ties: obj2, then input order -- the reference's tie order is a set order)
+ *   truncation (flags & TRUSS_FRONT_TRUNCATE, train copy): fronts longer than max_front keep both ends and
+ *               the max_front-2 interior points of largest crowding distance, in obj1 order.  DEVIATION:
+ *               the reference draws the interior points with random.sample (utils.py:118-123) and keeps
+ *               them in draw order; a batched kernel has no Python RNG stream to follow.
+ *   metrics   = [max_distance, dis_distance, p_norm_inv_cd, sum_distance, std_cd]  (utils.py:126-214)
+ *   hv_front  = union_rectangles_fastest(front, ref_point); hv_all = the same over ALL input rows
+ *               (the reference also calls it on raw archives).  Closed form over the x-sorted points
+ *               instead of the sweep + segment tree: same area, summation order differs (<= 1e-12).
+ * All pointers are device memory; outputs may be NULL to skip them.
+ */
+#define TRUSS_FRONT_TRUNCATE 0x1u
+#define TRUSS_FRONT_MAXP 64
+
+typedef struct truss_front_args {
+  size_t struct_size;
+  int32_t n_envs;
+  int32_t max_points;      /* P: row stride of points / front_idx (<= TRUSS_FRONT_MAXP) */
+  int32_t max_front;       /* MAX_FRONT (utils.py:6-7: 20 train, 50 test); used with TRUSS_FRONT_TRUNCATE */
+  uint32_t flags;
+  const double *points;    /* [B][P][4] */
+  const int32_t *n_points; /* [B] */
+  const double *ref_points;/* [B][2] or NULL = (1, 1) */
+  int32_t *front_idx;      /* [B][P]  input row of the k-th front point, -1 beyond n_front */
+  int32_t *n_front;        /* [B] */
+  double *hv_front;        /* [B] */
+  double *hv_all;          /* [B] */
+  double *metrics;         /* [B][5] */
+} truss_front_args_t;
+
+int truss_front(const truss_front_args_t *args, void *stream);
 
 #ifdef __cplusplus
 }

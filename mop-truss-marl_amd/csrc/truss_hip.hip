@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdio>
 
+#include "../../include/truss_mi355.h"
+
 #pragma clang fp contract(off)  // float32 decode arithmetic must round like numpy: no implicit FMA
 
 #define TRUSS_HD __device__ __forceinline__
@@ -138,6 +140,150 @@ __global__ __launch_bounds__(64) void truss_obs_kernel(const TopoDev T, const Ob
 #undef PH_NS
 }
 
+// ---- batched Pareto front + hypervolume (truss_front) ------------------------------------------------
+// One 64-lane wave per env, lane i <-> input row i (P <= 64 rows of [obj1, obj2, con1, con2]).  Everything
+// quadratic in P is a loop over LDS broadcast reads; the order-sensitive float64 sums (distances, area)
+// are accumulated by lane 0 in index order, like the Python loops they replace.
+__global__ __launch_bounds__(64) void truss_front_kernel(const truss_front_args_t A) {
+  __shared__ double px[64], py[64], pc1[64], pc2[64];      // input rows
+  __shared__ double sx[64], sy[64], sd[64], scr[64];        // front sorted by obj1; distances; crowding
+  __shared__ int sidx[64], keep[64];
+  __shared__ double ax[64], ay[64];                         // all rows sorted by clipped x (hv_all)
+  const int b = blockIdx.x, i = threadIdx.x, P = A.max_points;
+  int n = A.n_points[b];
+  n = n < 0 ? 0 : (n > P ? P : n);
+  const bool have = i < n;
+  const double *row = A.points + ((size_t)b * P + (have ? i : 0)) * 4;
+  const double x = row[0], y = row[1], c1 = row[2], c2 = row[3];
+  px[i] = x; py[i] = y; pc1[i] = c1; pc2[i] = c2;
+  __syncthreads();
+  const bool feas = have && !(c1 > 1.0 || c2 > 1.0);
+  bool dom = false, dup = false;
+  for (int j = 0; j < n; ++j) {
+    const bool fj = !(pc1[j] > 1.0 || pc2[j] > 1.0);
+    dom |= fj && px[j] < x && py[j] < y;
+    dup |= fj && j < i && px[j] == x && py[j] == y && pc1[j] == c1 && pc2[j] == c2;
+  }
+  const bool fr = feas && !dom && !dup;
+  // position in the front sorted by (obj1, obj2, input order); the same for all rows by clipped x
+  const double cx = fmin(x, 1.0), cy = fmin(y, 1.0);
+  keep[i] = fr ? 1 : 0;
+  __syncthreads();
+  int rank = 0, arank = 0;
+  for (int j = 0; j < n; ++j) {
+    rank += keep[j] && (px[j] < x || (px[j] == x && (py[j] < y || (py[j] == y && j < i))));
+    const double cxj = fmin(px[j], 1.0);
+    arank += (cxj < cx || (cxj == cx && j < i));
+  }
+  __syncthreads();
+  const unsigned long long fmask = __ballot(fr);
+  int nf = __popcll(fmask);
+  if (fr) { sx[rank] = x; sy[rank] = y; sidx[rank] = i; }
+  if (have) { ax[arank] = cx; ay[arank] = cy; }
+  __syncthreads();
+  // crowding distance on the sorted front (utils.py:96-110)
+  if (i + 1 < nf) {
+    const double dx = sx[i] - sx[i + 1], dy = sy[i] - sy[i + 1];
+    sd[i] = sqrt(dx * dx + dy * dy);
+  }
+  __syncthreads();
+  if (i < nf) scr[i] = nf == 1 ? 0.0 : (i == 0 ? sd[0] : (i == nf - 1 ? sd[nf - 2] : sd[i - 1] + sd[i]));
+  __syncthreads();
+  // truncation to max_front (train copy): both ends + the interior points of largest crowding distance
+  bool kp = i < nf;
+  if ((A.flags & TRUSS_FRONT_TRUNCATE) && nf > A.max_front) {
+    if (i > 0 && i < nf - 1) {
+      int cr = 0;
+      for (int j = 1; j < nf - 1; ++j) cr += (scr[j] > scr[i] || (scr[j] == scr[i] && j < i));
+      kp = cr < A.max_front - 2;
+    }
+  }
+  const unsigned long long kmask = __ballot(kp);
+  const int pos = __popcll(kmask & ((1ull << i) - 1ull));
+  const int nk = __popcll(kmask);
+  const double kx = i < nf ? sx[i] : 0.0, ky = i < nf ? sy[i] : 0.0;
+  const int kid = i < nf ? sidx[i] : -1;
+  __syncthreads();
+  if (kp) { sx[pos] = kx; sy[pos] = ky; keep[pos] = kid; }
+  nf = nk;
+  __syncthreads();
+  if (i + 1 < nf) {
+    const double dx = sx[i] - sx[i + 1], dy = sy[i] - sy[i + 1];
+    sd[i] = sqrt(dx * dx + dy * dy);
+  }
+  if (A.front_idx && i < P) A.front_idx[(size_t)b * P + i] = i < nf ? keep[i] : -1;
+  __syncthreads();
+  if (i != 0) return;
+  if (A.n_front) A.n_front[b] = nf;
+  const double rx = A.ref_points ? A.ref_points[2 * b] : 1.0, ry = A.ref_points ? A.ref_points[2 * b + 1] : 1.0;
+  if (A.metrics) {
+    double maxd = 0.0, disd = 1.0, sumd = 0.0, stdcd = 1.0, pn = 0.0;
+    if (nf >= 2) {
+      maxd = sd[0];
+      for (int k = 0; k < nf - 1; ++k) { maxd = sd[k] > maxd ? sd[k] : maxd; sumd += sd[k]; }
+      double acc = 0.0;
+      const double ctr = maxd / (nf - 1);            // sic: the reference centres on max/len (utils.py:131)
+      for (int k = 0; k < nf - 1; ++k) acc += (sd[k] - ctr) * (sd[k] - ctr);
+      disd = sqrt(acc / (nf - 1));
+    }
+    if (nf > 3) {
+      double s = 0.0, mx = 0.0;
+      for (int k = 1; k < nf - 1; ++k) {
+        const double cd = fabs(sx[k - 1] - sx[k + 1]) + fabs(sy[k - 1] - sy[k + 1]);
+        scr[k] = cd; s += cd; mx = cd > mx ? cd : mx;
+      }
+      if (s != 0.0) {
+        const int m = nf - 2;
+        double mean = 0.0;
+        for (int k = 1; k < nf - 1; ++k) { scr[k] = scr[k] / mx; mean += scr[k]; }
+        mean /= m;
+        double var = 0.0, p10 = 0.0;
+        for (int k = 1; k < nf - 1; ++k) {
+          const double v = scr[k], d = v - mean;
+          var += d * d;
+          const double v2 = v * v, v4 = v2 * v2;
+          p10 += v4 * v4 * v2;
+        }
+        stdcd = sqrt(var / m);
+        pn = pow(p10, 0.1);
+      }
+    }
+    double *M = A.metrics + (size_t)b * 5;
+    M[0] = maxd; M[1] = disd; M[2] = pn; M[3] = sumd; M[4] = stdcd;
+  }
+  if (A.hv_front) {      // the front is sorted by obj1 and its obj2 decreases: closed form of the union area
+    double hv = 0.0;
+    if (nf > 0 && !(nf == 1 && sx[0] == 1.0 && sy[0] == 1.0)) {
+      double area = 0.0, runmin = 1.0, minx = sx[0], miny = sy[0];
+      for (int k = 0; k < nf; ++k) {
+        const double cxk = fmin(sx[k], 1.0), cyk = fmin(sy[k], 1.0);
+        runmin = cyk < runmin ? cyk : runmin;
+        const double nx = k + 1 < nf ? fmin(sx[k + 1], 1.0) : 1.0;
+        area += (nx - cxk) * (1.0 - runmin);
+        minx = sx[k] < minx ? sx[k] : minx;
+        miny = sy[k] < miny ? sy[k] : miny;
+      }
+      hv = area - ((1.0 - rx) * (1.0 - minx) + (1.0 - ry) * (1.0 - miny) - (1.0 - rx) * (1.0 - ry));
+    }
+    A.hv_front[b] = hv;
+  }
+  if (A.hv_all) {
+    double hv = 0.0;
+    if (n > 0 && !(n == 1 && px[0] == 1.0 && py[0] == 1.0)) {
+      double area = 0.0, runmin = 1.0, minx = px[0], miny = py[0];
+      for (int k = 0; k < n; ++k) {
+        runmin = ay[k] < runmin ? ay[k] : runmin;
+        const double nx = k + 1 < n ? ax[k + 1] : 1.0;
+        area += (nx - ax[k]) * (1.0 - runmin);
+        minx = px[k] < minx ? px[k] : minx;
+        miny = py[k] < miny ? py[k] : miny;
+      }
+      hv = area - ((1.0 - rx) * (1.0 - minx) + (1.0 - ry) * (1.0 - miny) - (1.0 - rx) * (1.0 - ry));
+    }
+    A.hv_all[b] = hv;
+  }
+}
+
 // ---- host backend ---------------------------------------------------------------------------
 #define TRUSS_BACKEND_NAME "hip"
 struct truss_topo;
@@ -204,3 +350,13 @@ extern "C" int truss_debug_stamps(unsigned long long *out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_truss_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
+
+#include "truss_front.h"
+extern "C" int truss_front(const truss_front_args_t *a, void *stream) {
+  if (int rc = tb_front_check(a)) return rc;
+  if (a->n_envs == 0) return TRUSS_OK;
+  hipLaunchKernelGGL(truss_front_kernel, dim3((unsigned)a->n_envs), dim3(64), 0, (hipStream_t)stream, *a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("front kernel launch failed: ") + hipGetErrorString(e));
+  return TRUSS_OK;
+}

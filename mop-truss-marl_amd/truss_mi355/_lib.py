@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "csrc", "libtruss_mi355.so")
 
-TRUSS_ABI_VERSION = 1
+TRUSS_ABI_VERSION = 2
 F_NO_DECODE = 0x1
 F_CLAMP_INPLACE = 0x2
 NPARAM = 8
@@ -41,6 +41,18 @@ class ObsArgs(C.Structure):
         ("disp", _vp), ("q0", _vp), ("sr", _vp), ("comp", _vp), ("env_params", _vp),
         ("x_n", _vp), ("A_s", _vp), ("A_n_ts", _vp), ("A_n_cs", _vp), ("nN_x_n", _vp), ("nN_x_e", _vp),
     ]
+
+
+class FrontArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_size_t), ("n_envs", C.c_int32), ("max_points", C.c_int32), ("max_front", C.c_int32),
+        ("flags", C.c_uint32), ("points", _vp), ("n_points", _vp), ("ref_points", _vp), ("front_idx", _vp),
+        ("n_front", _vp), ("hv_front", _vp), ("hv_all", _vp), ("metrics", _vp),
+    ]
+
+
+F_FRONT_TRUNCATE = 0x1
+FRONT_MAXP = 64
 
 
 class TrussError(RuntimeError):
@@ -77,6 +89,8 @@ class TrussLib:
         if hasattr(d, "truss_obs"):
             d.truss_obs.restype = C.c_int
             d.truss_obs.argtypes = [_vp, C.POINTER(ObsArgs), _vp]
+        d.truss_front.restype = C.c_int
+        d.truss_front.argtypes = [C.POINTER(FrontArgs), _vp]
         if d.truss_abi_version() != TRUSS_ABI_VERSION:
             raise TrussError(f"{path}: ABI version {d.truss_abi_version()} != {TRUSS_ABI_VERSION}")
         self.backend = d.truss_backend().decode()

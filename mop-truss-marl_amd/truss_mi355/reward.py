@@ -1,0 +1,114 @@
+"""Batched Pareto front / hypervolume and the difference reward of the MADDPG loop (SURVEY.md §8 rows
+a23-a25) for B envs at once.
+
+`front_hv` is the host mirror of the C entry `truss_front` (include/truss_mi355.h): utils.simple_cull /
+simple_cull_final + utils.union_rectangles_fastest for a batch of small point sets, one wave per env.
+`difference_reward` restates the reward block of master_DDPG_truss2D_MO.run() (:263-368) on top of it:
+six launches (three leave-one-agent-out fronts, the full front, and the archive's own hypervolume with and
+without the reference point) plus a few elementwise float64 torch ops.
+
+Deviations from the per-env host path (master_DDPG_truss2D_MO.difference_reward), both documented in the
+header: (1) fronts longer than MAX_FRONT are truncated deterministically, not with random.sample;
+(2) the final sum is float64 throughout, the reference's is float32 where an agent is feasible (NEP-50),
+so R agrees to ~1e-6 relative.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def front_hv(points, n_points, ref_points=None, max_front=0, lib=None, stream=None):
+    """points [B,P,4] float64, n_points [B] int32 (device of the library's backend).
+    Returns dict(front_idx [B,P] int32, n_front [B] int32, hv_front [B], hv_all [B], metrics [B,5])."""
+    lib = lib or _lib.load()
+    B, P, four = points.shape
+    assert four == 4 and points.dtype == torch.float64 and points.is_contiguous()
+    assert n_points.dtype == torch.int32 and n_points.shape == (B,)
+    if P > _lib.FRONT_MAXP:
+        raise ValueError(f"at most {_lib.FRONT_MAXP} points per env")
+    dev = points.device
+    out = dict(front_idx=torch.empty((B, P), dtype=torch.int32, device=dev), n_front=torch.empty((B,), dtype=torch.int32, device=dev),
+               hv_front=torch.empty((B,), dtype=torch.float64, device=dev), hv_all=torch.empty((B,), dtype=torch.float64, device=dev),
+               metrics=torch.empty((B, 5), dtype=torch.float64, device=dev))
+    a = _lib.FrontArgs()
+    a.struct_size = C.sizeof(_lib.FrontArgs)
+    a.n_envs, a.max_points, a.max_front = B, P, int(max_front)
+    a.flags = _lib.F_FRONT_TRUNCATE if max_front else 0
+    a.points, a.n_points = _ptr(points), _ptr(n_points)
+    if ref_points is not None:
+        assert ref_points.dtype == torch.float64 and ref_points.shape == (B, 2) and ref_points.is_contiguous()
+    a.ref_points = _ptr(ref_points)
+    a.front_idx, a.n_front = _ptr(out["front_idx"]), _ptr(out["n_front"])
+    a.hv_front, a.hv_all, a.metrics = _ptr(out["hv_front"]), _ptr(out["hv_all"]), _ptr(out["metrics"])
+    if stream is None and dev.type == "cuda":
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    lib.check(lib.dll.truss_front(C.byref(a), stream), "truss_front")
+    return out
+
+
+def _append(base, n_base, extra, use):
+    """rows of `extra` [B,K,4] with use[B,K] appended (in order) behind the first n_base rows of base [B,P,4]."""
+    B, P, _ = base.shape
+    K = extra.shape[1]
+    out = torch.zeros((B, P + K, 4), dtype=torch.float64, device=base.device)
+    out[:, :P] = base
+    n = n_base.clone().to(torch.int64)
+    rows = torch.arange(B, device=base.device)
+    for k in range(K):
+        u = use[:, k]
+        idx = torch.where(u, n, torch.full_like(n, P + K - 1))          # unused rows land in a scratch slot ...
+        keep = out[rows, idx]
+        out[rows, idx] = torch.where(u[:, None], extra[:, k], keep)    # ... and leave it untouched
+        n = n + u.to(torch.int64)
+    return out, n.to(torch.int32)
+
+
+def difference_reward(front_no, n_front_no, pf_hv, n_pf_hv, parent, points, ref_points, n_pf, max_front=20, lib=None):
+    """Batched master_DDPG_truss2D_MO.difference_reward (:263-368).
+
+    front_no [B,P,4] / n_front_no [B]   current non-dominated archive rows
+    pf_hv    [B,P,4] / n_pf_hv    [B]   archive rows the step started from
+    parent   [B,2]                      (obj1, obj2) of the solution the agents acted on
+    points   [B,3,4]                    the three agents' new points
+    ref_points [B,2], n_pf [B]          reference point schedule, len(Pf)
+    returns R [B,3], G_U [B], xmax [B], ymax [B]   (float64 device tensors)"""
+    f64 = torch.float64
+    points = points.to(f64)
+    feas = (points <= 1.0).all(dim=2)                                   # _feasible: all four entries <= 1
+    hv_loo = []
+    for i in range(3):                                                  # leave agent i out
+        use = feas.clone()
+        use[:, i] = False
+        pts, n = _append(front_no, n_front_no, points, use)
+        hv_loo.append(front_hv(pts.contiguous(), n, ref_points, max_front, lib)["hv_front"])
+    pts, n = _append(front_no, n_front_no, points, feas)
+    full = front_hv(pts.contiguous(), n, ref_points, max_front, lib)
+    hyperV = full["hv_front"]
+    sum_distance, std_cd = full["metrics"][:, 3], full["metrics"][:, 4]
+    compareV = front_hv(pf_hv, n_pf_hv, ref_points, 0, lib)["hv_all"]
+    real_compareV = front_hv(pf_hv, n_pf_hv, None, 0, lib)["hv_all"]
+    zero = torch.zeros_like(hyperV)
+    hv = [torch.maximum(zero, h - compareV) for h in hv_loo]
+    hyperV = torch.maximum(zero, hyperV - compareV)
+    coef = ((1.0, 0.0), (0.5, 0.5), (0.0, 1.0))
+    npf = n_pf.to(f64)
+    m = torch.clamp(real_compareV, min=0.25)
+    R = []
+    for i in range(3):                                                  # both terms use point[0] (master…:348-352)
+        w = coef[i][0] * torch.clamp(parent[:, 0] - points[:, i, 0], min=0) + coef[i][1] * torch.clamp(parent[:, 1] - points[:, i, 0], min=0)
+        w = torch.where(feas[:, i], w, zero)
+        R.append(0.25 * w / (m * npf) + 0.25 * (hyperV - hv[i]) / (m * npf) + 10 * (real_compareV / npf)
+                 - 0.05 * torch.clamp(std_cd, 0, 1) / npf + 0.05 * sum_distance / (2 * m.sqrt() * npf))
+    G_U = 20 * real_compareV / npf - std_cd / npf + sum_distance / npf
+    big = torch.full_like(points[:, :, 0], -float("inf"))
+    xmax = torch.maximum(parent[:, 0], torch.where(feas, points[:, :, 0], big).max(dim=1).values)
+    ymax = torch.maximum(parent[:, 1], torch.where(feas, points[:, :, 1], big).max(dim=1).values)
+    return torch.stack(R, dim=1), G_U, xmax, ymax

@@ -89,3 +89,129 @@ static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *) {
   }
   return TRUSS_OK;
 }
+
+// ---- truss_front: serial restatement for the CPU test backend (the HIP kernel is in truss_hip.hip) ----
+#include "../../mop-truss-marl_amd/csrc/truss_front.h"
+#include <cmath>
+#include <vector>
+static double tb_hv_sorted(const std::vector<double> &cx, const std::vector<double> &cy, double minx, double miny, double rx,
+                           double ry) {
+  double area = 0.0, runmin = 1.0;
+  const int n = (int)cx.size();
+  for (int k = 0; k < n; ++k) {
+    runmin = cy[k] < runmin ? cy[k] : runmin;
+    const double nx = k + 1 < n ? cx[k + 1] : 1.0;
+    area += (nx - cx[k]) * (1.0 - runmin);
+  }
+  return area - ((1.0 - rx) * (1.0 - minx) + (1.0 - ry) * (1.0 - miny) - (1.0 - rx) * (1.0 - ry));
+}
+extern "C" int truss_front(const truss_front_args_t *a, void *) {
+  if (int rc = tb_front_check(a)) return rc;
+  const int P = a->max_points;
+  for (int b = 0; b < a->n_envs; ++b) {
+    int n = a->n_points[b];
+    n = n < 0 ? 0 : (n > P ? P : n);
+    const double *pt = a->points + (size_t)b * P * 4;
+    std::vector<int> fr;
+    for (int i = 0; i < n; ++i) {
+      const double *r = pt + 4 * i;
+      if (r[2] > 1.0 || r[3] > 1.0) continue;
+      bool out = false;
+      for (int j = 0; j < n && !out; ++j) {
+        const double *q = pt + 4 * j;
+        if (q[2] > 1.0 || q[3] > 1.0) continue;
+        if (q[0] < r[0] && q[1] < r[1]) out = true;
+        if (j < i && q[0] == r[0] && q[1] == r[1] && q[2] == r[2] && q[3] == r[3]) out = true;
+      }
+      if (!out) fr.push_back(i);
+    }
+    std::stable_sort(fr.begin(), fr.end(), [&](int u, int v) {
+      const double *p = pt + 4 * u, *q = pt + 4 * v;
+      return p[0] < q[0] || (p[0] == q[0] && p[1] < q[1]);
+    });
+    auto dist = [&](int u, int v) {
+      const double dx = pt[4 * u] - pt[4 * v], dy = pt[4 * u + 1] - pt[4 * v + 1];
+      return std::sqrt(dx * dx + dy * dy);
+    };
+    int nf = (int)fr.size();
+    if ((a->flags & TRUSS_FRONT_TRUNCATE) && nf > a->max_front) {
+      std::vector<double> cr(nf, 0.0);
+      for (int k = 0; k < nf; ++k)
+        cr[k] = k == 0 ? dist(fr[0], fr[1]) : (k == nf - 1 ? dist(fr[nf - 2], fr[nf - 1]) : dist(fr[k - 1], fr[k]) + dist(fr[k], fr[k + 1]));
+      std::vector<int> mid;
+      for (int k = 1; k < nf - 1; ++k) mid.push_back(k);
+      std::stable_sort(mid.begin(), mid.end(), [&](int u, int v) { return cr[u] > cr[v]; });
+      std::vector<char> kp(nf, 0);
+      kp[0] = kp[nf - 1] = 1;
+      for (int k = 0; k < a->max_front - 2; ++k) kp[mid[k]] = 1;
+      std::vector<int> f2;
+      for (int k = 0; k < nf; ++k)
+        if (kp[k]) f2.push_back(fr[k]);
+      fr.swap(f2);
+      nf = (int)fr.size();
+    }
+    if (a->front_idx)
+      for (int k = 0; k < P; ++k) a->front_idx[(size_t)b * P + k] = k < nf ? fr[k] : -1;
+    if (a->n_front) a->n_front[b] = nf;
+    const double rx = a->ref_points ? a->ref_points[2 * b] : 1.0, ry = a->ref_points ? a->ref_points[2 * b + 1] : 1.0;
+    if (a->metrics) {
+      double maxd = 0.0, disd = 1.0, sumd = 0.0, stdcd = 1.0, pn = 0.0;
+      std::vector<double> d;
+      for (int k = 0; k + 1 < nf; ++k) d.push_back(dist(fr[k], fr[k + 1]));
+      if (nf >= 2) {
+        for (double v : d) { maxd = v > maxd ? v : maxd; sumd += v; }
+        double acc = 0.0;
+        for (double v : d) acc += (v - maxd / d.size()) * (v - maxd / d.size());
+        disd = std::sqrt(acc / d.size());
+      }
+      if (nf > 3) {
+        std::vector<double> cd;
+        double s = 0.0, mx = 0.0;
+        for (int k = 1; k < nf - 1; ++k) {
+          const double v = std::fabs(pt[4 * fr[k - 1]] - pt[4 * fr[k + 1]]) + std::fabs(pt[4 * fr[k - 1] + 1] - pt[4 * fr[k + 1] + 1]);
+          cd.push_back(v); s += v; mx = v > mx ? v : mx;
+        }
+        if (s != 0.0) {
+          double mean = 0.0, var = 0.0, p10 = 0.0;
+          for (double &v : cd) { v /= mx; mean += v; }
+          mean /= cd.size();
+          for (double v : cd) { var += (v - mean) * (v - mean); p10 += std::pow(v, 10.0); }
+          stdcd = std::sqrt(var / cd.size());
+          pn = std::pow(p10, 0.1);
+        }
+      }
+      double *M = a->metrics + (size_t)b * 5;
+      M[0] = maxd; M[1] = disd; M[2] = pn; M[3] = sumd; M[4] = stdcd;
+    }
+    if (a->hv_front) {
+      double hv = 0.0;
+      if (nf > 0 && !(nf == 1 && pt[4 * fr[0]] == 1.0 && pt[4 * fr[0] + 1] == 1.0)) {
+        std::vector<double> cx, cy;
+        double minx = pt[4 * fr[0]], miny = pt[4 * fr[0] + 1];
+        for (int k : fr) {
+          cx.push_back(std::fmin(pt[4 * k], 1.0)); cy.push_back(std::fmin(pt[4 * k + 1], 1.0));
+          minx = std::fmin(minx, pt[4 * k]); miny = std::fmin(miny, pt[4 * k + 1]);
+        }
+        hv = tb_hv_sorted(cx, cy, minx, miny, rx, ry);
+      }
+      a->hv_front[b] = hv;
+    }
+    if (a->hv_all) {
+      double hv = 0.0;
+      if (n > 0 && !(n == 1 && pt[0] == 1.0 && pt[1] == 1.0)) {
+        std::vector<int> o(n);
+        for (int k = 0; k < n; ++k) o[k] = k;
+        std::stable_sort(o.begin(), o.end(), [&](int u, int v) { return std::fmin(pt[4 * u], 1.0) < std::fmin(pt[4 * v], 1.0); });
+        std::vector<double> cx, cy;
+        double minx = pt[0], miny = pt[1];
+        for (int k : o) {
+          cx.push_back(std::fmin(pt[4 * k], 1.0)); cy.push_back(std::fmin(pt[4 * k + 1], 1.0));
+          minx = std::fmin(minx, pt[4 * k]); miny = std::fmin(miny, pt[4 * k + 1]);
+        }
+        hv = tb_hv_sorted(cx, cy, minx, miny, rx, ry);
+      }
+      a->hv_all[b] = hv;
+    }
+  }
+  return TRUSS_OK;
+}

@@ -135,7 +135,7 @@ def test_hip_library_exports_every_declared_symbol():
     dll.truss_backend.restype = ctypes.c_char_p
     assert dll.truss_backend() == b"hip"
     dll.truss_abi_version.restype = ctypes.c_int
-    assert dll.truss_abi_version() == 1
+    assert dll.truss_abi_version() == 2
 
 
 def test_product_refuses_non_hip_default(monkeypatch, tmp_path):
