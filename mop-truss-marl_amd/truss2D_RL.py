@@ -343,7 +343,23 @@ class MADDPG:
             torch.save({"actor": ag.actor_model.state_dict(), "critic": ag.critic_model.state_dict()},
                        "{}Agent{}_pickle.pt".format(prefix, i + 1))
 
+    def load_tf_actors(self, prefix):
+        """Restore the actors (and target actors) from the reference's published TensorFlow checkpoints
+        `<prefix>Agent{i}_Actor_pickle.{index,data-00000-of-00001}` (master…:721-729; model/2000pickle_base).
+        Critic shards are not published; critics keep their initialisation.  Returns parameters copied."""
+        import tf_checkpoint
+        n = 0
+        for i, ag in enumerate(self.agents):
+            path = "{}Agent{}_Actor_pickle".format(prefix, i + 1)
+            n += tf_checkpoint.load_gcn_actor(ag.actor_model, path)
+            tf_checkpoint.load_gcn_actor(ag.target_actor_model, path)
+        return n
+
     def load_weights(self, prefix):
+        import os
+        if not os.path.exists("{}Agent1_pickle.pt".format(prefix)) and os.path.exists("{}Agent1_Actor_pickle.index".format(prefix)):
+            self.load_tf_actors(prefix)          # a directory written by the reference (TensorFlow format)
+            return
         for i, ag in enumerate(self.agents):
             sd = torch.load("{}Agent{}_pickle.pt".format(prefix, i + 1), weights_only=True, map_location=self.device)
             ag.actor_model.load_state_dict(sd["actor"])
