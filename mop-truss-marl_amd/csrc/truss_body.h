@@ -60,7 +60,7 @@ typedef double tb_d2 __attribute__((ext_vector_type(2)));
 typedef uint32_t tb_u4 __attribute__((vector_size(16)));
 typedef double tb_d2 __attribute__((vector_size(16)));
 #endif
-// 16-byte LDS row access (ds_read_b128 / ds_write_b128): band rows and rings are 16-byte aligned
+// 16-byte LDS row access (ds_read_b128 / ds_write_b128): band rows are 16-byte aligned
 TRUSS_HD void tb_ld_row(const double *p, double *dst, int n2) {
   const tb_d2 *q = (const tb_d2 *)__builtin_assume_aligned(p, 16);
   for (int i = 0; i < n2; ++i) {
@@ -99,7 +99,7 @@ struct TopoDev {
   double e_mod, long_stress;
   // LDS layout of the step kernel: [blob copy][env 0][env 1]...; o_* are byte offsets inside one env
   int32_t o_env0, env_stride;
-  int32_t o_kb, o_zs, o_dinv, o_xsol, o_red, o_rbuf, o_par, o_y, o_x, o_tg, o_geo, o_tac, o_sec, o_ev, o_zring, o_mrg;
+  int32_t o_kb, o_zs, o_xsol, o_red, o_rbuf, o_par, o_y, o_x, o_tg, o_geo, o_tac, o_sec, o_ev, o_zring, o_mrg;
   // output staging rows inside the (dead) band region, each 16-byte aligned
   int32_t so_q0, so_sr, so_disp, so_mu, so_md, so_comp;
 };
@@ -133,9 +133,10 @@ TRUSS_HD float tb_clamp01(float v) { return v > 1.0f ? 1.0f : (v < 0.0f ? 0.0f :
 // Python round(np.float32, 2): rint(v*100)/100 in float32 (truss2D_ENV.py:413)
 TRUSS_HD float tb_round2(float v) { return rintf(v * 100.0f) / 100.0f; }
 
-// G lanes own one env; the solver window is WL lanes x RPL rows (W = WL*RPL columns).  When G > WL the
-// extra lanes mirror lane g % WL through the solver (same registers, same LDS addresses) and only
-// contribute in the per-node / per-element phases.
+// G lanes own one env; the solver window is WL lanes x RPL rows (W = WL*RPL columns).  With G >= 2 WL and
+// one row per lane the second group of WL lanes is a second TEAM that eliminates the reversed system from
+// the other end (two-sided scheme, see the solver section); any further lanes mirror lane g % WL through the
+// solver (same registers, same LDS addresses) and only contribute in the per-node / per-element phases.
 template <int G, int WL, int RPL, int EPL>
 struct StepLane {
   static constexpr int W = WL * RPL;
@@ -166,11 +167,9 @@ struct StepLane {
 
   TRUSS_HD double *kb(const TopoDev &T) { return (double *)(L + T.o_kb); }
   TRUSS_HD double *zs(const TopoDev &T) { return (double *)(L + T.o_zs); }
-  TRUSS_HD double *dinv(const TopoDev &T) { return (double *)(L + T.o_dinv); }
   TRUSS_HD double *xsol(const TopoDev &T) { return (double *)(L + T.o_xsol); }
   TRUSS_HD double *red(const TopoDev &T) { return (double *)(L + T.o_red); }
   TRUSS_HD double *rbuf(const TopoDev &T) { return (double *)(L + T.o_rbuf); }
-  TRUSS_HD double *zring(const TopoDev &T) { return (double *)(L + T.o_zring); }
   TRUSS_HD double *par(const TopoDev &T) { return (double *)(L + T.o_par); }
   TRUSS_HD float *ysh(const TopoDev &T) { return (float *)(L + T.o_y); }
   TRUSS_HD float *xsh(const TopoDev &T) { return (float *)(L + T.o_x); }
@@ -600,9 +599,20 @@ struct StepLane {
   }
 
   // ---- solver -------------------------------------------------------------------------------
-  // Every routine below works in the lane's TEAM FRAME (Kt/Zt/Dt/ZRt): team A on the system as
-  // ordered by the host, team B (only when NT == 2) on the same system with rows and columns
-  // reversed.  The code is identical for both; only the LDS bases differ.
+  // K x = P with K SPD and banded (half-bandwidth < W), as L D L^T without square roots:
+  //   factorisation + forward substitution: pivot_write / pivot_update (one LDS exchange per pivot: every
+  //     lane posts its entry of column k, all read the column back; rows enter the window from
+  //     registers fetched once per block of W pivots, factor_rows_fetch);
+  //   two-sided scheme (nteams == 2): team A eliminates rows 0..KA-1 of the system as ordered by the host,
+  //     team B the last KA rows of the reversed system, merge_post / merge_take fold B's Schur complement
+  //     into A's window, A factorises the middle block;
+  //   back substitution, distributed: backsub_rows_fetch / backsub_step / backsub_share (owner lanes, DPP
+  //     broadcast of x_k), outwards from the middle in both teams (backsub_flush_mid / backsub_reload hand
+  //     the middle solutions to team B through the LDS).
+  // Every routine below works in the lane's TEAM FRAME (Kt / Zt / ZRt): the code is identical for both
+  // teams; only the LDS bases differ.  LDS stores are the expensive instruction here (the store path is
+  // shared by the four waves of a CU, ~40 cycles per wave-instruction under load),
+  // which is why nothing is stored that can stay in registers or be recomputed.
   TRUSS_HD void solver_init(const TopoDev &T) {
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
@@ -727,7 +737,7 @@ struct StepLane {
 
   // back substitution, distributed over the lanes of the team:
   //   x_k = (z_k - sum_m A[k+m,k] x_{k+m}) / d_k
-  // Row k of the factor (the posted pivot column k, {z_k, 1/d_k}) is needed by ONE dot product.  Each
+  // Row k of the factor (the posted pivot column k with the pivot d_k in it, and z_k) is needed by ONE dot product.  Each
   // lane therefore loads only the rows it owns -- row kb + gs (+ WL s) of a block of W steps, one set of
   // loads per block instead of one per step and lane -- evaluates every step's dot product with its own
   // row (only the owner's result means anything), and the owner's x_k reaches the other lanes of the

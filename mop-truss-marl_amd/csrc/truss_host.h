@@ -493,7 +493,6 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   {
     size_t o0 = off;
     D.o_zs = carve(sizeof(double) * (size_t)zlen * nteams);  // z vector per team (zlen is even)
-    D.o_dinv = D.o_zs;
     D.o_xsol = carve(sizeof(double) * (zslot + 4));  // + zero slot, dummy slot, 16-byte fill
     D.o_rbuf = carve(sizeof(double) * std::max(t->n_rest, 1));
     D.o_zring = carve(sizeof(double) * W * nteams);   // per-lane trash slots
