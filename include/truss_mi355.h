@@ -226,6 +226,16 @@ typedef struct truss_front_args {
 
 int truss_front(const truss_front_args_t *args, void *stream);
 
+/* ---- GCN neighbourhood aggregation for the actors' inference in batched rollouts -----------------
+ * replaces (inference only): the `A @ (X W) + b` + activation half of spektral GCNConv as used by
+ * truss2D_RL.multimodes_actor (truss2D_RL.py:49-120): out[b][i][c] = act(sum_j A[b][i][j] H[b][j][c] + bias[c])
+ * with H = X W computed by the caller (one large GEMM, rocBLAS).  float32; n_nodes <= 64.
+ * a_batch_stride = n_nodes * n_nodes for per-env adjacencies, 0 for one adjacency shared by the batch.
+ * act: 0 none, 1 relu, 2 sigmoid.  Device pointers; `out` may alias `h`.
+ */
+int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, const float *h, const float *bias, float *out,
+                        int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -360,3 +360,50 @@ extern "C" int truss_front(const truss_front_args_t *a, void *stream) {
   if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("front kernel launch failed: ") + hipGetErrorString(e));
   return TRUSS_OK;
 }
+
+// ---- GCN aggregation (inference): one workgroup per env and 256 channels, thread = channel -------------
+// Memory-bound (reads H once, writes out once, 16-64 FMAs per element): every global access is a contiguous
+// run of channels across the threads of a wave; the adjacency row block sits in LDS and is read as a
+// broadcast.  Bias and activation are fused (no extra passes over the [B, N, C] tensor).
+template <int NMAX>
+__global__ __launch_bounds__(256) void truss_gcn_aggregate_kernel(const float *__restrict__ adj, long a_stride, const float *h,
+                                                                  const float *__restrict__ bias, float *out, int N, int C, int act) {
+  __shared__ float sA[NMAX * NMAX];
+  const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  const float *A = adj + (size_t)b * a_stride;
+  for (int i = threadIdx.x; i < N * N; i += 256) sA[i] = A[i];
+  __syncthreads();
+  if (c >= C) return;
+  const float *H = h + (size_t)b * N * C + c;
+  float col[NMAX];
+#pragma unroll
+  for (int j = 0; j < NMAX; ++j) col[j] = j < N ? H[(size_t)j * C] : 0.0f;
+  const float bc = bias ? bias[c] : 0.0f;
+  float *O = out + (size_t)b * N * C + c;
+  for (int i = 0; i < N; ++i) {
+    float acc = bc;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) acc = fmaf(j < N ? sA[i * N + j] : 0.0f, col[j], acc);
+    if (act == 1) acc = acc > 0.0f ? acc : 0.0f;
+    else if (act == 2) acc = 1.0f / (1.0f + expf(-acc));
+    O[(size_t)i * C] = acc;
+  }
+}
+
+extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, const float *h, const float *bias, float *out,
+                                   int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act, void *stream) {
+  if (!adj || !h || !out) return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: NULL argument");
+  if (n_batch < 0 || n_nodes < 1 || n_nodes > 64 || n_channels < 1 || act < 0 || act > 2)
+    return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: n_nodes must be 1..64, act 0..2");
+  if (n_batch == 0) return TRUSS_OK;
+  dim3 grid((unsigned)n_batch, (unsigned)((n_channels + 255) / 256));
+  if (n_nodes <= 16)
+    hipLaunchKernelGGL(truss_gcn_aggregate_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, adj, (long)a_batch_stride, h, bias, out, n_nodes, n_channels, act);
+  else if (n_nodes <= 32)
+    hipLaunchKernelGGL(truss_gcn_aggregate_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, adj, (long)a_batch_stride, h, bias, out, n_nodes, n_channels, act);
+  else
+    hipLaunchKernelGGL(truss_gcn_aggregate_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, adj, (long)a_batch_stride, h, bias, out, n_nodes, n_channels, act);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("gcn aggregate launch failed: ") + hipGetErrorString(e));
+  return TRUSS_OK;
+}

@@ -286,6 +286,13 @@ class MADDPG:
         NS = [self._state_tensors([v[8 + f] for v in samples]) for f in range(3)]
         A = [(t(1), t(2)), (t(3), t(4)), (t(5), t(6))]
         R = torch.as_tensor(np.array([v[7] for v in samples]), dtype=torch.float32, device=self.device)   # [B,3]
+        self.train_on_batch(S, NS, A, R)
+
+    def train_on_batch(self, S, NS, A, R):
+        """One MADDPG update (truss2D_RL.py:536-689) on a prepared minibatch of device tensors:
+        S = [x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p] (batch first), NS = the same per agent's next state
+        (three lists), A = [(a_geo, a_topo)] x 3, R [batch, 3].  `train()` feeds it from the host replay of
+        the reference loop; the batched rollout (truss_mi355/marl.py) from its device replay."""
         flat = lambda order: [A[order[0]][0], A[order[0]][1], A[order[1]][0], A[order[1]][1], A[order[2]][0], A[order[2]][1]]
         orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]          # (self, other1, other2) per agent (:561-563)
         self._ensure_ready(S, flat(orders[0]))

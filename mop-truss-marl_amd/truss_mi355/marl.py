@@ -1,0 +1,308 @@
+"""Batched multi-agent rollout + training loop (BASELINE configs 3-5: thousands of envs with the MADDPG
+agents in the loop).  The reference's `run()` (master_DDPG_truss2D_MO.py:164-705) plays ONE truss: per game
+step it lets the three agents modify every member of the Pareto archive, scores the moves with the
+hypervolume-difference reward, culls the archive and trains.  Here the same game step runs for B trusses at
+once, every piece on the device:
+
+    parents' analysis + observation   BatchedTruss.analyze / observe     (truss_step, truss_obs kernels)
+    three agents' actions             truss2D_RL actors on a [B, N, .] batch (rocBLAS)
+    the 3 B candidate designs         one truss_step launch over 3 B envs (+ truss_obs for the next states)
+    rewards                           reward.difference_reward            (truss_front kernel)
+    archive update                    reward.front_hv + gathers
+    replay + MADDPG update            device tensors, MADDPG.train_on_batch
+
+Differences from the per-env loop, all forced by batching and documented here:
+  D1  the archive is culled after every archive member's three candidates instead of once per game step
+      (the Pareto front of a union is the front of the partial fronts, so the resulting set is the same
+      unless the MAX_FRONT truncation intervenes); rewards still use the front at the START of the game
+      step, like the reference (front_no / Pf_HV, :263-368);
+  D2  a transition enters the replay when its candidate is accepted into the archive at insertion time
+      (the reference remembers the candidates that survive the end-of-step cull, :595-621);
+  D3  truncation to MAX_FRONT is deterministic (largest crowding distance), see include/truss_mi355.h;
+  D4  when an agent's move is infeasible its next state in the replay is the first feasible agent's
+      (the reference draws a random survivor, :380-407); the Pareto-graph inputs (x_p, A_p) of the next
+      states are those of the step-start front;
+  D5  exploration noise is drawn on the device (same law as truss2D_RL.OUNoise: theta (mu - a) dt + sigma N(0,1)).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import reward as RW
+from .batched import BatchedTruss
+from .topology import TrussTopology
+
+
+def pareto_graph(pts, n, index, max_front):
+    """Batched truss2D_ENV.pareto_state_data (:19-38) + zero padding to P nodes (master…:488-593).
+    pts [B,P,4] (rows beyond n ignored), n [B], index [B] -> x_p [B,P,4], A_p [B,P,P] float32."""
+    B, P, _ = pts.shape
+    dev = pts.device
+    ar = torch.arange(P, device=dev)
+    valid = ar[None, :] < n[:, None]
+    x = torch.zeros((B, P, 4), dtype=torch.float32, device=dev)
+    x[:, :, 0] = pts[:, :, 0].float()
+    x[:, :, 1] = pts[:, :, 1].float()
+    x[:, :, 2] = (ar[None, :] == index[:, None]).float()
+    x[:, :, 3] = (n.float() / max_front)[:, None]
+    x = x * valid[:, :, None]
+    A = torch.zeros((B, P, P), dtype=torch.float32, device=dev)
+    vf = valid.float()
+    A[:, ar, ar] = vf
+    e = (vf[:, :-1] * vf[:, 1:])
+    A[:, ar[:-1], ar[1:]] = e
+    A[:, ar[1:], ar[:-1]] = e
+    deg = A.sum(dim=2)
+    d = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    return x, d[:, :, None] * A * d[:, None, :]
+
+
+def gcn_aggregate(lib, adj, h, bias, act):
+    """act(adj @ h + bias) through the fused HIP kernel `truss_gcn_aggregate` (inference only, float32).
+    adj [N,N] (shared) or [B,N,N]; h [B,N,C] contiguous; act in {None,'relu','sigmoid'}."""
+    import ctypes as C
+    B, N, Cc = h.shape
+    adj = adj.contiguous()
+    stride = 0 if adj.dim() == 2 or adj.shape[0] == 1 else N * N
+    out = torch.empty_like(h)
+    stream = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream) if h.is_cuda else None
+    code = {None: 0, "relu": 1, "sigmoid": 2}[act]
+    lib.check(lib.dll.truss_gcn_aggregate(C.c_void_p(adj.data_ptr()), stride, C.c_void_p(h.data_ptr()),
+                                          C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, N, Cc, code, stream),
+              "truss_gcn_aggregate")
+    return out
+
+
+def actor_infer(lib, actor, ins):
+    """truss2D_RL.multimodes_actor.forward (truss2D_RL.py:49-120) for inference: the dense half of every
+    GCN layer (X W) stays a rocBLAS GEMM over the whole batch, the neighbourhood aggregation + bias +
+    activation is one fused kernel per layer instead of a batched 16x16 GEMM and two elementwise passes."""
+    x_n, A_n, A_s, A_ts, A_cs, x_p, A_p = ins
+
+    def g(layer, x, a, act="relu"):
+        if not layer._init:                       # lazy layers: let the module materialise itself once
+            with torch.no_grad():
+                layer(x[:1], a[:1] if a.dim() == 3 else a)
+        return gcn_aggregate(lib, a, layer.lin(x).contiguous(), layer.bias, act)
+
+    a = actor
+    x11, x12, x13 = g(a.gcn_l1_1, x_n, A_n), g(a.gcn_l1_2, x_n, A_n), g(a.gcn_l1_3, x_n, A_n)
+    x14 = g(a.gcn_l1_4, x_p, A_p).sum(dim=1)
+    B, H = x14.shape
+    x14 = x14.unsqueeze(-1).expand(B, H, x11.shape[1]).reshape(B, x11.shape[1], H)      # _tile_pool (:87-93)
+    x3 = (g(a.gcn_l2_1, x11, A_n) + g(a.gcn_l2_2, x12, A_ts) + g(a.gcn_l2_3, x12, A_cs) + g(a.gcn_l2_4, x13, A_s)
+          + g(a.gcn_l2_5, x14.contiguous(), A_n))
+    x31, x32 = g(a.gcn_l3_1, x3, A_n), g(a.gcn_l3_2, x3, A_s)
+    return g(a.gcn_l4_1, x31, A_n, "sigmoid"), g(a.gcn_l4_2, x32, A_n, "sigmoid")
+
+
+class DeviceReplay:
+    """Ring buffer of transitions in device memory (state / three next states as the eight observation
+    tensors the networks take minus the topology-static A_n and mask, three agents' actions, rewards)."""
+
+    KEYS = ("x_n", "A_s", "A_n_ts", "A_n_cs", "x_p", "A_p")
+
+    def __init__(self, capacity, N, P, device):
+        f = lambda *s: torch.zeros((capacity,) + s, dtype=torch.float32, device=device)
+        shapes = dict(x_n=(N, 13), A_s=(N, N), A_n_ts=(N, N), A_n_cs=(N, N), x_p=(P, 4), A_p=(P, P))
+        self.S = {k: f(*shapes[k]) for k in self.KEYS}
+        self.NS = [{k: f(*shapes[k]) for k in self.KEYS} for _ in range(3)]
+        self.a_geo, self.a_topo, self.R = f(3, N, 2), f(3, N, 3), f(3)
+        self.capacity, self.size, self.head = capacity, 0, 0
+
+    def add(self, sel, S, NS, a_geo, a_topo, R):
+        """append the transitions of the envs where sel[B] is True"""
+        idx = torch.nonzero(sel, as_tuple=False).flatten()
+        k = int(idx.numel())
+        if k == 0:
+            return 0
+        if k > self.capacity:
+            idx, k = idx[: self.capacity], self.capacity
+        pos = (self.head + torch.arange(k, device=idx.device)) % self.capacity
+        for key in self.KEYS:
+            self.S[key][pos] = S[key][idx]
+            for a in range(3):
+                self.NS[a][key][pos] = NS[a][key][idx]
+        self.a_geo[pos], self.a_topo[pos], self.R[pos] = a_geo[idx], a_topo[idx], R[idx]
+        self.head = (self.head + k) % self.capacity
+        self.size = min(self.capacity, self.size + k)
+        return k
+
+    def sample(self, batch, generator=None):
+        i = torch.randint(0, self.size, (batch,), device=self.R.device, generator=generator)
+        pick = lambda d: {k: v[i] for k, v in d.items()}
+        return pick(self.S), [pick(ns) for ns in self.NS], self.a_geo[i], self.a_topo[i], self.R[i]
+
+
+class BatchedMARL:
+    def __init__(self, topo: TrussTopology, n_envs: int, maddpg, *, max_front: int = 20, lib=None, device=None,
+                 replay_capacity: int = 32768, batch_size: int = 32, hv_margin: float = 0.2, seed: int = 0):
+        self.topo, self.B, self.P = topo, int(n_envs), int(max_front)
+        self.rl = maddpg
+        self.envP = BatchedTruss(topo, self.B, device=device, lib=lib)          # archive members under study
+        self.envC = BatchedTruss(topo, 3 * self.B, device=device, lib=lib)      # their candidates, agent-major
+        self.lib, self.device = self.envP.lib, self.envP.device
+        dev, B, P, N, E = self.device, self.B, self.P, topo.N, topo.E
+        A_n, mask = topo.normalized_adjacency()
+        self.A_n = torch.tensor(A_n, device=dev)[None]
+        self.mask = torch.tensor(mask, device=dev)[None]
+        self.pts = torch.zeros((B, P, 4), dtype=torch.float64, device=dev)
+        self.arch_y = torch.zeros((B, P, N), dtype=torch.float32, device=dev)
+        self.arch_sec = torch.zeros((B, P, E), dtype=torch.int32, device=dev)
+        self.n = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.ref_points = torch.ones((B, 2), dtype=torch.float64, device=dev)
+        self.replay = DeviceReplay(replay_capacity, N, P, dev)
+        self.batch_size, self.hv_margin = batch_size, hv_margin
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self.game_step = 1
+        self._steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
+        self.profile = None            # set to {} to accumulate synchronised wall time per segment (diagnostic)
+
+    def _tick(self, name, t0):
+        if self.profile is None:
+            return t0
+        import time
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        self.profile[name] = self.profile.get(name, 0.0) + (t1 - t0)
+        return t1
+
+    @property
+    def env_steps(self):
+        """agent modifications evaluated so far (3 per live archive member per game step)"""
+        return int(self._steps_dev.item())
+
+    # ---- episode set-up (Game_research04.__init__ / ENV.reset / run() prologue, :164-196) ----
+    def reset(self, x, target, y_max, d_min, max_def, load_x, load_y, is_roof, y0, sec0):
+        def tiled(a, rep):                                   # per-env arrays [B] / [B, N] -> [rep B, ...]; scalars as they are
+            a = np.asarray(a, np.float64)
+            if a.ndim == 0:
+                return a
+            a = np.broadcast_to(a, (self.B,) + a.shape[1:]) if a.shape[0] != self.B else a
+            return np.tile(a, (rep,) + (1,) * (a.ndim - 1))
+        for env, rep in ((self.envP, 1), (self.envC, 3)):
+            env.set_constants(*[tiled(a, rep) for a in (x, target, y_max, d_min, max_def, load_x, load_y, is_roof)])
+        self.envP.set_design(y0, sec0)
+        self.envP.analyze(set_normalisers=True)
+        self.envC.env_params.copy_(self.envP.env_params.repeat(3, 1))
+        self.pts.zero_(); self.arch_y.zero_(); self.arch_sec.zero_()
+        self.pts[:, 0, 0:2] = 1.0                                    # Pf = [[1, 1, 0, 0, S0, ...]] (:168)
+        self.arch_y[:, 0] = self.envP.y
+        self.arch_sec[:, 0] = self.envP.sec
+        self.n.fill_(1)
+        self.ref_points.fill_(1.0)
+        self.game_step = 1
+
+    # ---- observation tensors in the networks' order ----
+    def _obs(self, env, pts0, n0, index, rep=1):
+        o = env.observe()
+        x_p, A_p = pareto_graph(pts0, n0, index, self.P)
+        if rep > 1:
+            x_p, A_p = x_p.repeat(rep, 1, 1), A_p.repeat(rep, 1, 1)
+        return dict(x_n=o["x_n"].clone(), A_s=o["A_s"].clone(), A_n_ts=o["A_n_ts"].clone(), A_n_cs=o["A_n_cs"].clone(), x_p=x_p, A_p=A_p)
+
+    def _net_state(self, S):
+        b = S["x_n"].shape[0]
+        return [S["x_n"], self.A_n.expand(b, -1, -1), S["A_s"], S["A_n_ts"], S["A_n_cs"], self.mask.expand(b, -1, -1), S["x_p"], S["A_p"]]
+
+    def _act(self, S, explore):
+        ins = self._net_state(S)
+        actor_in = [ins[0], ins[1], ins[2], ins[3], ins[4], ins[6], ins[7]]
+        geo, topo = [], []
+        with torch.no_grad():
+            for ag in self.rl.agents:
+                g, t = actor_infer(self.lib, ag.actor_model, [actor_in[0], self.A_n[0], actor_in[2], actor_in[3], actor_in[4],
+                                                              actor_in[5], actor_in[6]])
+                if explore:                                           # truss2D_RL.OUNoise.gen_noise per scalar (:41-48)
+                    for out, noises in ((g, ag.noise_geo), (t, ag.noise_topo)):
+                        for j, nz in enumerate(noises):
+                            out[:, :, j] += nz.theta * (nz.mu - out[:, :, j]) * nz.dt + nz.sigma * torch.randn(
+                                out[:, :, j].shape, device=out.device, generator=self.gen)
+                geo.append(g.float().contiguous())
+                topo.append(t.float().contiguous())
+        return geo, topo
+
+    # ---- one game step of every env (run() :198-705) ----
+    def game_step_all(self, train: bool = True, explore: bool = True, train_iters: int = 1):
+        B, P = self.B, self.P
+        pts0, n0 = self.pts.clone(), self.n.clone()                   # front_no / Pf_HV of this step (:203-209)
+        y0, sec0 = self.arch_y.clone(), self.arch_sec.clone()
+        added = 0
+        rsum = torch.zeros((B, 3), dtype=torch.float64, device=self.device)
+        import time
+        tk = time.perf_counter()
+        for m in range(int(n0.max().item())):
+            tk = self._tick("other", tk)
+            active = n0 > m
+            idx_m = torch.full((B,), m, dtype=torch.int64, device=self.device)
+            # parents: member m of the step-start archive (:211-221)
+            self.envP.y.copy_(y0[:, m]); self.envP.sec.copy_(sec0[:, m])
+            self.envP.analyze()
+            S = self._obs(self.envP, pts0, n0, idx_m)
+            tk = self._tick("parent analysis + obs", tk)
+            geo, topo = self._act(S, explore)
+            tk = self._tick("actors", tk)
+            # the three agents modify the SAME parent (:249-260): one launch over 3 B envs
+            self.envC.y.copy_(y0[:, m].repeat(3, 1)); self.envC.sec.copy_(sec0[:, m].repeat(3, 1))
+            a_geo, a_topo = torch.cat(geo, 0).contiguous(), torch.cat(topo, 0).contiguous()
+            self.envC.step(a_geo, a_topo, clamp_inplace=True)         # clamped actions go to the replay (:375)
+            self._steps_dev += 3 * active.sum()
+            NSall = self._obs(self.envC, pts0, n0, idx_m, rep=3)
+            tk = self._tick("candidate step + obs", tk)
+            points = self.envC.point.view(3, B, 4).permute(1, 0, 2).double().contiguous()
+            cand_y = self.envC.y.view(3, B, -1).permute(1, 0, 2)
+            cand_sec = self.envC.sec.view(3, B, -1).permute(1, 0, 2)
+            R, _, _, _ = RW.difference_reward(pts0, n0, pts0, n0, pts0[:, m, :2].contiguous(), points, self.ref_points, n0,
+                                              max_front=P, lib=self.lib)
+            rsum += torch.where(active[:, None], R, torch.zeros_like(R))
+            tk = self._tick("reward", tk)
+            ok = (points[:, :, 2] <= 1) & (points[:, :, 3] <= 1) & active[:, None]      # archive candidates (:372)
+            # ---- archive update (D1): front of (working archive + feasible candidates) ----
+            allp = torch.cat([self.pts, points], dim=1).clone()
+            ar = torch.arange(P, device=self.device)
+            dead = torch.cat([ar[None, :] >= self.n[:, None], ~ok], dim=1)
+            allp[:, :, 2] = torch.where(dead, torch.full_like(allp[:, :, 2], 2.0), allp[:, :, 2])   # infeasible marker
+            fr = RW.front_hv(allp.contiguous(), torch.full((B,), P + 3, dtype=torch.int32, device=self.device), None,
+                             max_front=P, lib=self.lib)
+            fidx = fr["front_idx"][:, :P].long()
+            take = fidx.clamp(min=0)
+            ally = torch.cat([self.arch_y, cand_y], dim=1)
+            alls = torch.cat([self.arch_sec, cand_sec], dim=1)
+            origp = torch.cat([self.pts, points], dim=1)
+            rows = torch.arange(B, device=self.device)[:, None]
+            live = fidx >= 0
+            self.pts = torch.where(live[:, :, None], origp[rows, take], torch.zeros_like(self.pts))
+            self.pts[:, :, 0:2] = torch.minimum(self.pts[:, :, 0:2], torch.ones_like(self.pts[:, :, 0:2]))   # :434-436
+            self.arch_y = torch.where(live[:, :, None], ally[rows, take], torch.zeros_like(self.arch_y))
+            self.arch_sec = torch.where(live[:, :, None], alls[rows, take], torch.zeros_like(self.arch_sec))
+            self.n = fr["n_front"].clamp(max=P)
+            tk = self._tick("archive update", tk)
+            # ---- replay (D2): one row per accepted candidate ----
+            if train:
+                accepted = torch.stack([(fidx == P + a).any(dim=1) for a in range(3)], dim=1) & ok
+                first_ok = torch.argmax(ok.int(), dim=1)                                   # D4
+                pick = lambda key, a: NSall[key].view(3, B, *NSall[key].shape[1:])[a]
+                NS = []
+                for a in range(3):
+                    src = torch.where(ok[:, a], torch.full_like(first_ok, a), first_ok)
+                    NS.append({k: torch.stack([pick(k, s) for s in range(3)], 0)[src, torch.arange(B, device=self.device)]
+                               for k in DeviceReplay.KEYS})
+                ag = a_geo.view(3, B, -1, 2).permute(1, 0, 2, 3)
+                at = a_topo.view(3, B, -1, 3).permute(1, 0, 2, 3)
+                added += self.replay.add(accepted.any(dim=1), S, NS, ag, at, R.float())
+            tk = self._tick("replay", tk)
+        # ---- end of the game step (:430-473, 642) ----
+        hv = RW.front_hv(self.pts.contiguous(), self.n, None, 0, self.lib)
+        self.ref_points = torch.clamp(self.ref_points + self.hv_margin, max=1.0)
+        self.game_step += 1
+        if train and self.replay.size >= self.batch_size:
+            for _ in range(train_iters):
+                S, NS, ag, at, R = self.replay.sample(self.batch_size, self.gen)
+                A = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
+                self.rl.train_on_batch(self._net_state(S), [self._net_state(ns) for ns in NS], A, R)
+        tk = self._tick("train", tk)
+        return dict(hv=hv["hv_front"], n_front=self.n.clone(), sum_distance=hv["metrics"][:, 3], reward=rsum, replay_added=added,
+                    replay_size=self.replay.size)

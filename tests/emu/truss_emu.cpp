@@ -215,3 +215,25 @@ extern "C" int truss_front(const truss_front_args_t *a, void *) {
   }
   return TRUSS_OK;
 }
+
+extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, const float *h, const float *bias, float *out,
+                                   int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act, void *) {
+  if (!adj || !h || !out) return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: NULL argument");
+  if (n_batch < 0 || n_nodes < 1 || n_nodes > 64 || n_channels < 1 || act < 0 || act > 2)
+    return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: n_nodes must be 1..64, act 0..2");
+  const int N = n_nodes, C = n_channels;
+  std::vector<float> tmp((size_t)N * C);
+  for (int b = 0; b < n_batch; ++b) {
+    const float *A = adj + (size_t)b * a_batch_stride, *H = h + (size_t)b * N * C;
+    for (int i = 0; i < N; ++i)
+      for (int c = 0; c < C; ++c) {
+        float acc = bias ? bias[c] : 0.0f;
+        for (int j = 0; j < N; ++j) acc = std::fmaf(A[i * N + j], H[(size_t)j * C + c], acc);
+        if (act == 1) acc = acc > 0.0f ? acc : 0.0f;
+        else if (act == 2) acc = 1.0f / (1.0f + std::exp(-acc));
+        tmp[(size_t)i * C + c] = acc;
+      }
+    std::copy(tmp.begin(), tmp.end(), out + (size_t)b * N * C);
+  }
+  return TRUSS_OK;
+}

@@ -1,0 +1,119 @@
+"""Batched MARL game steps (truss_mi355/marl.py, BASELINE configs 3-5) on the CPU backend: archive
+invariants, consistency of rewards / archive update with the per-env host path, replay and training."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import truss_mi355 as tm
+from truss_mi355 import marl, reward as RW, synthetic
+import parity_common as pc
+import utils as U
+import master_DDPG_truss2D_MO as M
+import truss2D_RL as RL
+
+
+def _engine(lib, device, B=6, num_x=4, seed=3):
+    topo = tm.TrussTopology.grid(num_x)
+    torch.manual_seed(seed)
+    rl = RL.MADDPG(M.lr, M.ep, M.epd, M.gamma, 16, 8, 100, M.num_agents, M.num_action, M.mu, M.theta, M.sigma, device=device)
+    eng = marl.BatchedMARL(topo, B, rl, max_front=6, lib=lib, device=device, replay_capacity=256, batch_size=8, seed=seed)
+    b = synthetic.random_batch(topo, B, seed)
+    eng.reset(b["x"], b["target"], b["y_max"], b["d_min"], b["max_def"], b["load_x"], b["load_y"], b["is_roof"], b["y"], b["sec"])
+    return eng
+
+
+def _run(lib, device):
+    eng = _engine(lib, device)
+    B, P = eng.B, eng.P
+    assert int(eng.n.min()) == 1 and torch.all(eng.pts[:, 0, :2] == 1.0)
+    calls = []
+    orig = RW.difference_reward
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        calls.append(([t.clone() if torch.is_tensor(t) else t for t in a], [o.clone() for o in out]))
+        return out
+
+    RW.difference_reward = spy
+    marl.RW.difference_reward = spy
+    try:
+        w0 = [p.detach().clone() for p in eng.rl.agents[0].actor_model.parameters() if not isinstance(p, torch.nn.parameter.UninitializedParameter)]
+        stats = [eng.game_step_all(train=True, explore=True, train_iters=2) for _ in range(3)]
+    finally:
+        RW.difference_reward = orig
+        marl.RW.difference_reward = orig
+    # archive invariants: 1 <= n <= P, rows sorted by obj1, mutually non-dominated, feasible, clipped to <= 1
+    pts, n = eng.pts.cpu().numpy(), eng.n.cpu().numpy()
+    for b in range(B):
+        assert 1 <= n[b] <= P
+        rows = pts[b, :n[b]]
+        assert np.all(rows[:, :2] <= 1.0) and np.all(rows[:, 2:] <= 1.0)
+        assert list(rows[:, 0]) == sorted(rows[:, 0])
+        for i in range(n[b]):
+            assert not any(rows[j, 0] < rows[i, 0] and rows[j, 1] < rows[i, 1] for j in range(n[b]))
+    # every reward call agrees with the per-env host reward block on the same inputs
+    args, outs = calls[0]
+    front, nf, pf, npf, parent, points, ref, n_pf = [a.cpu().numpy() if torch.is_tensor(a) else a for a in args[:8]]
+    for b in range(B):
+        want = M.difference_reward([list(r) for r in front[b, :nf[b]]], [list(r) for r in pf[b, :npf[b]]], tuple(parent[b]),
+                                   [list(p) for p in points[b]], list(ref[b]), int(n_pf[b]))
+        np.testing.assert_allclose(outs[0][b].cpu().numpy(), want[:3], rtol=1e-9, atol=1e-11)
+    # the stored designs reproduce their archived points (analysis of the archive = its points)
+    chk = tm.BatchedTruss(eng.topo, B, device=device, lib=lib)
+    chk.x.copy_(eng.envP.x); chk.target.copy_(eng.envP.target); chk.env_params.copy_(eng.envP.env_params)
+    for m in range(int(n.max())):
+        chk.y.copy_(eng.arch_y[:, m]); chk.sec.copy_(eng.arch_sec[:, m])
+        chk.analyze()
+        got = chk.point.cpu().numpy().astype(np.float64)
+        for b in range(B):
+            if m < n[b] and not (pts[b, m, 2] == 0.0 and pts[b, m, 3] == 0.0):   # the initial member is archived as [1, 1, 0, 0] (master…:168)
+                np.testing.assert_allclose(np.minimum(got[b, :2], 1.0), pts[b, m, :2], rtol=1e-6)
+                np.testing.assert_allclose(got[b, 2:], pts[b, m, 2:], rtol=1e-6, atol=1e-9)
+    assert stats[-1]["replay_size"] >= 1 and eng.env_steps >= 3 * B
+    w1 = [p.detach() for p in eng.rl.agents[0].actor_model.parameters()]
+    assert eng.replay.size < eng.batch_size or any(not torch.equal(a, b) for a, b in zip(w0, w1[: len(w0)])) or len(w0) == 0
+    assert torch.isfinite(stats[-1]["hv"]).all()
+
+
+def test_batched_marl_emulated():
+    with contextlib.redirect_stdout(io.StringIO()):
+        _run(pc.emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_batched_marl_hip():
+    with contextlib.redirect_stdout(io.StringIO()):
+        _run(tm.load(), "cuda")
+
+
+def _check_actor_infer(lib, device):
+    """fused GCN aggregation (truss_gcn_aggregate) vs the plain PyTorch float32 actor"""
+    torch.manual_seed(0)
+    B, N, P = 37, 16, 20
+    actor = RL.multimodes_actor(200, 2, 3).to(device)
+    r = lambda *s: torch.rand(*s, device=device)
+    A = lambda n: torch.softmax(torch.randn(B, n, n, device=device), dim=-1)
+    ins = [r(B, N, 13), A(N)[0], A(N), A(N), A(N), r(B, P, 4), A(P)]
+    with torch.no_grad():
+        ref = actor([ins[0], ins[1][None].expand(B, -1, -1)] + ins[2:])
+        got = marl.actor_infer(lib, actor, ins)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+    h = r(B, 24, 70)                                   # odd sizes, per-env adjacency, every activation
+    adj = A(24)
+    bias = r(70)
+    for act, f in ((None, lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
+        torch.testing.assert_close(marl.gcn_aggregate(lib, adj, h, bias, act), f(torch.matmul(adj, h) + bias), rtol=2e-5, atol=2e-6)
+
+
+def test_actor_infer_emulated():
+    _check_actor_infer(pc.emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_actor_infer_hip():
+    _check_actor_infer(tm.load(), "cuda")
