@@ -333,6 +333,25 @@ class MADDPG:
             _clip_each(ap)
             torch.optim.Adam(ap, lr=ag.lr * 0.1, eps=1e-7).step()       # a fresh optimiser every call
 
+    def sync_parameters(self, src=0):
+        """Data-parallel start: every rank takes rank `src`'s actor / critic / target weights (one broadcast
+        of a flat buffer per network).  Call once the lazy layers exist (after the first forward)."""
+        d = self.dist
+        if d is None or not d.is_initialized() or d.get_world_size() == 1:
+            return
+        for ag in self.agents:
+            for net in (ag.actor_model, ag.target_actor_model, ag.critic_model, ag.target_critic_model):
+                ps = [p for p in net.parameters() if not isinstance(p, nn.parameter.UninitializedParameter)]
+                if not ps:
+                    continue
+                flat = torch.cat([p.detach().reshape(-1) for p in ps])
+                d.broadcast(flat, src=src)
+                off = 0
+                with torch.no_grad():
+                    for p in ps:
+                        p.copy_(flat[off:off + p.numel()].view_as(p))
+                        off += p.numel()
+
     def update(self):
         interval = len(self.agents) * 100
         if self.agents[0].update_num % interval == 0:

@@ -158,6 +158,7 @@ class BatchedMARL:
         self.gen.manual_seed(seed)
         self.game_step = 1
         self._steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._synced = False
         self.profile = None            # set to {} to accumulate synchronised wall time per segment (diagnostic)
 
     def _tick(self, name, t0):
@@ -298,7 +299,23 @@ class BatchedMARL:
         hv = RW.front_hv(self.pts.contiguous(), self.n, None, 0, self.lib)
         self.ref_points = torch.clamp(self.ref_points + self.hv_margin, max=1.0)
         self.game_step += 1
-        if train and self.replay.size >= self.batch_size:
+        ready = train and self.replay.size >= self.batch_size
+        d = getattr(self.rl, "dist", None)
+        if train and d is not None and d.is_initialized() and d.get_world_size() > 1:
+            # data parallel: every rank plays its own envs and replay; the update is collective
+            # (fused gradient all-reduce inside train_on_batch), so all ranks must agree to run it
+            flag = torch.tensor([1 if ready else 0], device=self.device)
+            d.all_reduce(flag, op=d.ReduceOp.MIN)
+            ready = bool(flag.item())
+        if ready:
+            if not self._synced:
+                with torch.no_grad():                                     # materialise lazy layers, then one broadcast
+                    S, NS, ag, at, R = self.replay.sample(2, self.gen)
+                    A = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
+                    st = self._net_state(S)
+                    self.rl._ensure_ready(st, [A[0][0], A[0][1], A[1][0], A[1][1], A[2][0], A[2][1]])
+                self.rl.sync_parameters()
+                self._synced = True
             for _ in range(train_iters):
                 S, NS, ag, at, R = self.replay.sample(self.batch_size, self.gen)
                 A = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]

@@ -66,3 +66,50 @@ def test_two_rank_sharded_rollout():
     np.testing.assert_array_equal(np.array(per_rank), np.array(want))
     np.testing.assert_allclose(np.array(total), np.array(want).sum(axis=0), rtol=1e-15)
     assert not np.array_equal(want[0], want[1])      # the shards really are different envs
+
+
+def _marl_worker(rank, world, port, lib_path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    import truss_mi355 as tm
+    from truss_mi355 import synthetic, marl
+    import master_DDPG_truss2D_MO as M
+    import truss2D_RL as RL
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = tm.load(lib_path)
+    topo = tm.TrussTopology.grid(4)
+    torch.manual_seed(100 + rank)                          # DIFFERENT initial weights per rank: the broadcast must fix that
+    rl = RL.MADDPG(M.lr, M.ep, M.epd, M.gamma, 16, 8, 100, M.num_agents, M.num_action, M.mu, M.theta, M.sigma, device="cpu", dist=dist)
+    eng = marl.BatchedMARL(topo, 5, rl, max_front=6, lib=lib, device="cpu", replay_capacity=128, batch_size=4, seed=rank)
+    b = synthetic.random_batch(topo, 5, 50 + rank)         # each rank plays its own envs
+    eng.reset(b["x"], b["target"], b["y_max"], b["d_min"], b["max_def"], b["load_x"], b["load_y"], b["is_roof"], b["y"], b["sec"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        for _ in range(3):
+            eng.game_step_all(train=True, explore=True)
+    sig = torch.stack([torch.cat([p.detach().double().reshape(-1) for p in net.parameters()]).sum()
+                       for ag in rl.agents for net in (ag.actor_model, ag.critic_model)])
+    got = [torch.zeros_like(sig) for _ in range(world)]
+    dist.all_gather(got, sig)
+    if rank == 0:
+        out.put(([g.tolist() for g in got], eng.replay.size, eng.env_steps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_marl():
+    """BASELINE config 4 in miniature: two ranks, each with its own envs / archive / replay, one MADDPG whose
+    gradients are all-reduced (fused flat buffer) -> identical weights on both ranks after training."""
+    lib_path = pc.build_emu()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_marl_worker, args=(r, 2, port, lib_path, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sigs, replay, steps = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert replay >= 4 and steps >= 15
+    np.testing.assert_allclose(sigs[0], sigs[1], rtol=1e-12)
