@@ -141,6 +141,7 @@ template <int G, int WL, int RPL, int EPL>
 struct StepLane {
   static constexpr int W = WL * RPL;
   static constexpr int WL_ = WL;
+  static constexpr int NPL = (2 * EPL + 4) / 5;   // nodes per lane unrolled (two-row grid trusses: N ~ 0.4 E)
   static constexpr int EPB = 64 / G;  // envs per wave
   static constexpr int NDEG = 8;      // unrolled node-degree bound of the diagonal gather
   static constexpr int NT = G / WL;   // solver teams per env (1, or 2 = two-sided elimination)
@@ -562,7 +563,7 @@ struct StepLane {
     const double *EV = evsh(T);
     const int16_t *AD = t_adj8(T), *DO = t_diagoff(T);
     double *K = kb(T);
-    for (int n = g; n < T.N; n += G) {
+    auto node = [&](int n) {
       double cc = 0.0, cs = 0.0, ss = 0.0;
 #pragma unroll
       for (int a = 0; a < NDEG; ++a) {
@@ -574,7 +575,16 @@ struct StepLane {
       K[DO[3 * n]] = cc;      // restrained DOFs point at the trash slot
       K[DO[3 * n + 1]] = ss;
       K[DO[3 * n + 2]] = cs;
+    };
+    // the first NPL nodes of a lane are unrolled with clamped indices (a duplicate recomputes and rewrites the
+    // same values): the two levels of dependent LDS gathers of different nodes overlap instead of queueing
+    // behind a loop with a run-time trip count; topologies with more nodes per lane take the plain loop
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = g + G * i;
+      node(n < T.N ? n : T.N - 1);
     }
+    for (int n = g + G * NPL; n < T.N; n += G) node(n);
     // identity rows: team A beyond its part + middle; team B beyond the middle (its middle rows keep a
     // zero diagonal: they are never pivots of team B)
     const int idA = T.nteams == 1 ? T.ndof : T.ndof - T.KA;
@@ -587,9 +597,19 @@ struct StepLane {
     double *Z = zs(T);
     const uint8_t *ZC = t_zcode(T);
     const int lbit = is_roof ? 4 : 2;
-    for (int r = g; r < T.zlen * T.nteams; r += G) {   // load vector P in each team's frame (host table)
-      const int c = ZC[r];
-      Z[r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
+    {   // load vector P in each team's frame (host table); unrolled with clamped indices like the node loops
+      const int zt = T.zlen * T.nteams;
+      constexpr int ZIT = 6;
+#pragma unroll
+      for (int i = 0; i < ZIT; ++i) {
+        const int r0 = g + G * i, r = r0 < zt ? r0 : zt - 1;
+        const int c = ZC[r];
+        Z[r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
+      }
+      for (int r = g + G * ZIT; r < zt; r += G) {
+        const int c = ZC[r];
+        Z[r] = (c & lbit) ? ((c & 1) ? load_y : load_x) : 0.0;
+      }
     }
     tb_d2 *X2 = (tb_d2 *)__builtin_assume_aligned(xsol(T), 16);
     const tb_d2 z2 = {0.0, 0.0};
@@ -884,23 +904,29 @@ struct StepLane {
     const size_t bn = (size_t)envc * T.N;
     const int zslot = T.zslot;
     float *DS = odisp(T), *MU = omu(T), *MD = omd(T);
-    for (int n = g; n < T.N; n += G) {
+    auto node = [&](int n, bool real) {   // real = false: a clamped duplicate of node N-1 (loads and stores only)
       int px = DP[2 * n], py = DP[2 * n + 1];
       double dx = XS[px < 0 ? zslot : px], dy = XS[py < 0 ? zslot : py];
       bool top = NF[n] & TF_TOP;
       float y = Y[n];
       if (top) {
-        p_dt += (double)fabsf(TG[n] - y);  // all_dt (ENV:514)
+        p_dt += real ? (double)fabsf(TG[n] - y) : 0.0;  // all_dt (ENV:514)
       } else {
-        p_c2 = fmaxf(p_c2, fabsf((float)(dy / max_def)));  // all_d (ENV:516)
+        p_c2 = real ? fmaxf(p_c2, fabsf((float)(dy / max_def))) : p_c2;  // all_d (ENV:516)
       }
       DS[2 * n + 0] = (float)dx;
       DS[2 * n + 1] = (float)dy;
-      if (A.disp64 && active) {
+      if (A.disp64 && active && real) {
         A.disp64[(bn + n) * 2 + 0] = dx;
         A.disp64[(bn + n) * 2 + 1] = dy;
       }
+    };
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {       // unrolled like phase_assemble_nodes: the gathers of the lane's nodes overlap
+      const int n = g + G * i;
+      node(n < T.N ? n : T.N - 1, n < T.N);
     }
+    for (int n = g + G * NPL; n < T.N; n += G) node(n, true);
     if (A.mu_out && T.has_pairs) {
       for (int p = g; p < T.NP; p += G) {
         int lo = PR[2 * p], hi = PR[2 * p + 1];

@@ -33,7 +33,7 @@ struct TbVariant {
 #define TRUSS_VARIANTS(X) X(16, 8, 1, 5)
 #else
 #define TRUSS_VARIANTS(X) \
-  X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(8, 8, 2, 10) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20)
+  X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20)
 #endif
 static const TbVariant kVariants[] = {
 #define X(g, wl, r, e) {g, wl, r, e},

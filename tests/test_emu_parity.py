@@ -45,7 +45,7 @@ def test_symmetric_variants_random(lib):
     pc.run_random_rollout(lib, 16, 0, 6, 2, seed=6, symmetry="large")
 
 
-@pytest.mark.parametrize("G,WL,RPL", [(8, 8, 1), (16, 8, 1), (16, 16, 1), (8, 8, 2), (16, 8, 2), (4, 4, 2)])
+@pytest.mark.parametrize("G,WL,RPL", [(8, 8, 1), (16, 8, 1), (16, 16, 1), (16, 8, 2), (4, 4, 2)])
 def test_every_kernel_variant_emulated(lib, monkeypatch, G, WL, RPL):
     monkeypatch.setenv("TRUSS_LANES", str(G))
     monkeypatch.setenv("TRUSS_WLANES", str(WL))
@@ -155,8 +155,8 @@ def test_hip_kernels_use_no_scratch():
     names = re.findall(r"Function Name: (\S+)", txt)
     scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
     spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", txt)]
-    assert len(names) == len(scratch) == len(spills) and len(names) >= 9
-    assert sum("truss_step_kernel" in n for n in names) >= 8 and any("truss_obs_kernel" in n for n in names)
+    assert len(names) == len(scratch) == len(spills) and len(names) >= 8
+    assert sum("truss_step_kernel" in n for n in names) >= 7 and any("truss_obs_kernel" in n for n in names)
     assert all(v == 0 for v in scratch), dict(zip(names, scratch))
     # one-row-per-lane kernels (every shipped configuration): no spills at all.  The two-rows-per-lane
     # fallbacks for wide bands may park a register or two in the AGPR file (no memory traffic: scratch is 0).

@@ -124,7 +124,7 @@ def test_rollout_matches_stepwise(lib):
 
 def test_every_kernel_variant(lib, monkeypatch):
     """Each compiled lanes-per-env x rows-per-lane instantiation gives the same answers."""
-    for G, WL, RPL in [(8, 8, 1), (16, 8, 1), (16, 16, 1), (8, 8, 2), (16, 8, 2), (4, 4, 2)]:
+    for G, WL, RPL in [(8, 8, 1), (16, 8, 1), (16, 16, 1), (16, 8, 2), (4, 4, 2)]:
         monkeypatch.setenv("TRUSS_LANES", str(G))
         monkeypatch.setenv("TRUSS_WLANES", str(WL))
         monkeypatch.setenv("TRUSS_RPL", str(RPL))
