@@ -89,10 +89,10 @@ class BatchedTruss:
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
 
-    def _args(self, flags, a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy=True):
+    def _args(self, flags, a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy=True, n_envs=None):
         a = _lib.StepArgs()
         a.struct_size = C.sizeof(_lib.StepArgs)
-        a.n_envs, a.flags = self.B, flags
+        a.n_envs, a.flags = (self.B if n_envs is None else int(n_envs)), flags
         a.x, a.y_in, a.sec_in = _ptr(self.x), _ptr(y_in), _ptr(sec_in)
         a.max_up_in, a.max_down_in = _ptr(mu_in), _ptr(md_in)
         a.a_geo, a.a_topo, a.coin = _ptr(a_geo), _ptr(a_topo), _ptr(coin)
@@ -134,11 +134,21 @@ class BatchedTruss:
         self.sec.copy_(torch.as_tensor(np.broadcast_to(np.asarray(sec, np.int32), (self.B, self.E)).copy(),
                                        device=self.device))
 
-    def analyze(self, set_normalisers: bool = False):
+    def _n(self, n_active):
+        if n_active is None:
+            return self.B
+        n = int(n_active)
+        if not 0 <= n <= self.B:
+            raise ValueError(f"n_active {n} outside 0..{self.B}")
+        return n
+
+    def analyze(self, set_normalisers: bool = False, n_active=None):
         """Model.restore(); Model.gen_all() on the current design (reset path).  With
         set_normalisers the raw objectives become int_obj1/int_obj2 (Game_research04.__init__,
-        truss2D_ENV.py:264-274)."""
-        a = self._args(_lib.F_NO_DECODE, None, None, None, None, None, self.y, self.sec, self.y, self.sec)
+        truss2D_ENV.py:264-274).  n_active: only the first n envs of the resident buffers (callers that
+        compact their live envs to the front, truss_mi355/marl.py)."""
+        a = self._args(_lib.F_NO_DECODE, None, None, None, None, None, self.y, self.sec, self.y, self.sec,
+                       n_envs=self._n(n_active))
         self.lib.check(self.lib.dll.truss_step(self.h, C.byref(a), self._stream()), "truss_step(analyze)")
         if set_normalisers:
             self.env_params[:, _lib.P_INTOBJ1] = self.obj[:, 0].double()
@@ -147,10 +157,10 @@ class BatchedTruss:
             self.point[:, 1] = 1.0
 
     # ---- the transition ---------------------------------------------------------------------
-    def step(self, a_geo, a_topo, coin=None, max_up_in=None, max_down_in=None, clamp_inplace=False):
+    def step(self, a_geo, a_topo, coin=None, max_up_in=None, max_down_in=None, clamp_inplace=False, n_active=None):
         """One `_game_modify` per env from the current design; the new design becomes current.
-        a_geo [B,N,2], a_topo [B,N,3] float32 on the env's device."""
-        B, N = self.B, self.N
+        a_geo [B,N,2], a_topo [B,N,3] float32 on the env's device ([n_active, ...] with n_active)."""
+        B, N = self._n(n_active), self.N
         if coin is None:
             coin = self._coin0
         nxt = self.cur ^ 1
@@ -158,16 +168,17 @@ class BatchedTruss:
         # an RL loop passes the same buffers every step: validated argument blocks are kept per buffer set
         key = (self.cur, flags, a_geo.data_ptr(), a_topo.data_ptr(), coin.data_ptr(),
                0 if max_up_in is None else max_up_in.data_ptr(), 0 if max_down_in is None else max_down_in.data_ptr(),
-               a_geo.shape, a_topo.shape)
+               a_geo.shape, a_topo.shape, B)
         a = self._step_cache.get(key)
         if a is None:
             self._chk(a_geo, (B, N, 2), torch.float32, "a_geo")
             self._chk(a_topo, (B, N, 3), torch.float32, "a_topo")
-            self._chk(coin, (B,), torch.uint8, "coin")
+            if coin is not self._coin0:
+                self._chk(coin, (B,), torch.uint8, "coin")
             self._chk(max_up_in, (B, N), torch.float32, "max_up_in")
             self._chk(max_down_in, (B, N), torch.float32, "max_down_in")
             a = self._args(flags, a_geo, a_topo, coin, max_up_in, max_down_in, self.ybuf[self.cur], self.secbuf[self.cur],
-                           self.ybuf[nxt], self.secbuf[nxt])
+                           self.ybuf[nxt], self.secbuf[nxt], n_envs=B)
             if len(self._step_cache) > 64:
                 self._step_cache.clear()
             self._step_cache[key] = a
@@ -192,7 +203,7 @@ class BatchedTruss:
         if n_steps & 1:
             self.cur = nxt
 
-    def observe(self, out=None):
+    def observe(self, out=None, n_active=None):
         """state_data + state_data_not_norm (truss2D_ENV.py:40-193) for the current design and the last
         analysis, for every env: x_n[B,N,13], A_s/A_n_ts/A_n_cs[B,N,N], nN_x_n[B,N,12], nN_x_e[B,E,21]
         (device tensors).  A_n, mask and nC_e are topology-static: TrussTopology.normalized_adjacency()
@@ -205,8 +216,9 @@ class BatchedTruss:
                 self._obs = dict(x_n=mk(B, N, 13), A_s=mk(B, N, N), A_n_ts=mk(B, N, N), A_n_cs=mk(B, N, N),
                                  nN_x_n=mk(B, N, 12), nN_x_e=mk(B, E, 21))
             out = self._obs
-        key = (self.cur, id(out)) + tuple(0 if out.get(k) is None else out[k].data_ptr()
-                                          for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e"))
+        nact = self._n(n_active)
+        key = (self.cur, id(out), nact) + tuple(0 if out.get(k) is None else out[k].data_ptr()
+                                                for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e"))
         a = self._obs_cache.get(key)
         if a is not None:
             rc = self.lib.dll.truss_obs(self.h, C.byref(a), self._stream())
@@ -215,7 +227,7 @@ class BatchedTruss:
             return out
         a = _lib.ObsArgs()
         a.struct_size = C.sizeof(_lib.ObsArgs)
-        a.n_envs, a.flags = B, 0
+        a.n_envs, a.flags = nact, 0
         a.x, a.y, a.sec = _ptr(self.x), _ptr(self.y), _ptr(self.sec)
         a.max_up, a.max_down, a.target = _ptr(self.max_up), _ptr(self.max_down), _ptr(self.target)
         a.disp, a.q0, a.sr, a.comp = _ptr(self.disp), _ptr(self.q0), _ptr(self.sr), _ptr(self.comp)

@@ -189,6 +189,9 @@ class BatchedMARL:
         self.envP.set_design(y0, sec0)
         self.envP.analyze(set_normalisers=True)
         self.envC.env_params.copy_(self.envP.env_params.repeat(3, 1))
+        # per-env constants of the whole batch: the env objects are re-filled with the LIVE envs of every member
+        # iteration, compacted to the front (BatchedTruss n_active)
+        self.c_x, self.c_target, self.c_params = self.envP.x.clone(), self.envP.target.clone(), self.envP.env_params.clone()
         self.pts.zero_(); self.arch_y.zero_(); self.arch_sec.zero_()
         self.pts[:, 0, 0:2] = 1.0                                    # Pf = [[1, 1, 0, 0, S0, ...]] (:168)
         self.arch_y[:, 0] = self.envP.y
@@ -198,12 +201,14 @@ class BatchedMARL:
         self.game_step = 1
 
     # ---- observation tensors in the networks' order ----
-    def _obs(self, env, pts0, n0, index, rep=1):
-        o = env.observe()
+    def _obs(self, env, pts0, n0, index, rep=1, k=None):
+        k = env.B if k is None else k
+        o = env.observe(n_active=k)
         x_p, A_p = pareto_graph(pts0, n0, index, self.P)
         if rep > 1:
             x_p, A_p = x_p.repeat(rep, 1, 1), A_p.repeat(rep, 1, 1)
-        return dict(x_n=o["x_n"].clone(), A_s=o["A_s"].clone(), A_n_ts=o["A_n_ts"].clone(), A_n_cs=o["A_n_cs"].clone(), x_p=x_p, A_p=A_p)
+        c = lambda key: o[key][:k].clone()
+        return dict(x_n=c("x_n"), A_s=c("A_s"), A_n_ts=c("A_n_ts"), A_n_cs=c("A_n_cs"), x_p=x_p, A_p=A_p)
 
     def _net_state(self, S):
         b = S["x_n"].shape[0]
@@ -235,64 +240,77 @@ class BatchedMARL:
         rsum = torch.zeros((B, 3), dtype=torch.float64, device=self.device)
         import time
         tk = time.perf_counter()
+        dev = self.device
         for m in range(int(n0.max().item())):
             tk = self._tick("other", tk)
-            active = n0 > m
-            idx_m = torch.full((B,), m, dtype=torch.int64, device=self.device)
+            # live envs of this member index, compacted to the front of the env objects: the work of an
+            # iteration is proportional to the number of envs whose archive has a member m
+            idx = torch.nonzero(n0 > m, as_tuple=False).flatten()
+            K = int(idx.numel())
+            if K == 0:
+                break
+            p0, nn0 = pts0[idx].contiguous(), n0[idx].contiguous()
+            idx_m = torch.full((K,), m, dtype=torch.int64, device=dev)
+            py, ps = y0[idx, m], sec0[idx, m]
+            cx, ct, cp = self.c_x[idx], self.c_target[idx], self.c_params[idx]
             # parents: member m of the step-start archive (:211-221)
-            self.envP.y.copy_(y0[:, m]); self.envP.sec.copy_(sec0[:, m])
-            self.envP.analyze()
-            S = self._obs(self.envP, pts0, n0, idx_m)
+            eP, eC = self.envP, self.envC
+            eP.x[:K], eP.target[:K], eP.env_params[:K] = cx, ct, cp
+            eP.y[:K], eP.sec[:K] = py, ps
+            eP.analyze(n_active=K)
+            S = self._obs(eP, p0, nn0, idx_m, k=K)
             tk = self._tick("parent analysis + obs", tk)
             geo, topo = self._act(S, explore)
             tk = self._tick("actors", tk)
-            # the three agents modify the SAME parent (:249-260): one launch over 3 B envs
-            self.envC.y.copy_(y0[:, m].repeat(3, 1)); self.envC.sec.copy_(sec0[:, m].repeat(3, 1))
+            # the three agents modify the SAME parent (:249-260): one launch over 3 K envs, agent-major
+            eC.x[:3 * K], eC.target[:3 * K], eC.env_params[:3 * K] = cx.repeat(3, 1), ct.repeat(3, 1), cp.repeat(3, 1)
+            eC.y[:3 * K], eC.sec[:3 * K] = py.repeat(3, 1), ps.repeat(3, 1)
             a_geo, a_topo = torch.cat(geo, 0).contiguous(), torch.cat(topo, 0).contiguous()
-            self.envC.step(a_geo, a_topo, clamp_inplace=True)         # clamped actions go to the replay (:375)
-            self._steps_dev += 3 * active.sum()
-            NSall = self._obs(self.envC, pts0, n0, idx_m, rep=3)
+            eC.step(a_geo, a_topo, clamp_inplace=True, n_active=3 * K)   # clamped actions go to the replay (:375)
+            self._steps_dev += 3 * K
+            NSall = self._obs(eC, p0, nn0, idx_m, rep=3, k=3 * K)
             tk = self._tick("candidate step + obs", tk)
-            points = self.envC.point.view(3, B, 4).permute(1, 0, 2).double().contiguous()
-            cand_y = self.envC.y.view(3, B, -1).permute(1, 0, 2)
-            cand_sec = self.envC.sec.view(3, B, -1).permute(1, 0, 2)
-            R, _, _, _ = RW.difference_reward(pts0, n0, pts0, n0, pts0[:, m, :2].contiguous(), points, self.ref_points, n0,
-                                              max_front=P, lib=self.lib)
-            rsum += torch.where(active[:, None], R, torch.zeros_like(R))
+            points = eC.point[:3 * K].view(3, K, 4).permute(1, 0, 2).double().contiguous()
+            cand_y = eC.y[:3 * K].view(3, K, -1).permute(1, 0, 2)
+            cand_sec = eC.sec[:3 * K].view(3, K, -1).permute(1, 0, 2)
+            R, _, _, _ = RW.difference_reward(p0, nn0, p0, nn0, p0[:, m, :2].contiguous(), points, self.ref_points[idx].contiguous(),
+                                              nn0, max_front=P, lib=self.lib)
+            rsum[idx] += R
             tk = self._tick("reward", tk)
-            ok = (points[:, :, 2] <= 1) & (points[:, :, 3] <= 1) & active[:, None]      # archive candidates (:372)
+            ok = (points[:, :, 2] <= 1) & (points[:, :, 3] <= 1)                          # archive candidates (:372)
             # ---- archive update (D1): front of (working archive + feasible candidates) ----
-            allp = torch.cat([self.pts, points], dim=1).clone()
-            ar = torch.arange(P, device=self.device)
-            dead = torch.cat([ar[None, :] >= self.n[:, None], ~ok], dim=1)
+            wp, wy, ws, wn = self.pts[idx], self.arch_y[idx], self.arch_sec[idx], self.n[idx]
+            allp = torch.cat([wp, points], dim=1).clone()
+            ar = torch.arange(P, device=dev)
+            dead = torch.cat([ar[None, :] >= wn[:, None], ~ok], dim=1)
             allp[:, :, 2] = torch.where(dead, torch.full_like(allp[:, :, 2], 2.0), allp[:, :, 2])   # infeasible marker
-            fr = RW.front_hv(allp.contiguous(), torch.full((B,), P + 3, dtype=torch.int32, device=self.device), None,
+            fr = RW.front_hv(allp.contiguous(), torch.full((K,), P + 3, dtype=torch.int32, device=dev), None,
                              max_front=P, lib=self.lib)
             fidx = fr["front_idx"][:, :P].long()
             take = fidx.clamp(min=0)
-            ally = torch.cat([self.arch_y, cand_y], dim=1)
-            alls = torch.cat([self.arch_sec, cand_sec], dim=1)
-            origp = torch.cat([self.pts, points], dim=1)
-            rows = torch.arange(B, device=self.device)[:, None]
+            ally = torch.cat([wy, cand_y], dim=1)
+            alls = torch.cat([ws, cand_sec], dim=1)
+            origp = torch.cat([wp, points], dim=1)
+            rows = torch.arange(K, device=dev)[:, None]
             live = fidx >= 0
-            self.pts = torch.where(live[:, :, None], origp[rows, take], torch.zeros_like(self.pts))
-            self.pts[:, :, 0:2] = torch.minimum(self.pts[:, :, 0:2], torch.ones_like(self.pts[:, :, 0:2]))   # :434-436
-            self.arch_y = torch.where(live[:, :, None], ally[rows, take], torch.zeros_like(self.arch_y))
-            self.arch_sec = torch.where(live[:, :, None], alls[rows, take], torch.zeros_like(self.arch_sec))
-            self.n = fr["n_front"].clamp(max=P)
+            newp = torch.where(live[:, :, None], origp[rows, take], torch.zeros_like(wp))
+            newp[:, :, 0:2] = torch.minimum(newp[:, :, 0:2], torch.ones_like(newp[:, :, 0:2]))      # :434-436
+            self.pts[idx] = newp
+            self.arch_y[idx] = torch.where(live[:, :, None], ally[rows, take], torch.zeros_like(wy))
+            self.arch_sec[idx] = torch.where(live[:, :, None], alls[rows, take], torch.zeros_like(ws))
+            self.n[idx] = fr["n_front"].clamp(max=P)
             tk = self._tick("archive update", tk)
             # ---- replay (D2): one row per accepted candidate ----
             if train:
                 accepted = torch.stack([(fidx == P + a).any(dim=1) for a in range(3)], dim=1) & ok
                 first_ok = torch.argmax(ok.int(), dim=1)                                   # D4
-                pick = lambda key, a: NSall[key].view(3, B, *NSall[key].shape[1:])[a]
+                ark = torch.arange(K, device=dev)
                 NS = []
                 for a in range(3):
                     src = torch.where(ok[:, a], torch.full_like(first_ok, a), first_ok)
-                    NS.append({k: torch.stack([pick(k, s) for s in range(3)], 0)[src, torch.arange(B, device=self.device)]
-                               for k in DeviceReplay.KEYS})
-                ag = a_geo.view(3, B, -1, 2).permute(1, 0, 2, 3)
-                at = a_topo.view(3, B, -1, 3).permute(1, 0, 2, 3)
+                    NS.append({k: NSall[k].view(3, K, *NSall[k].shape[1:])[src, ark] for k in DeviceReplay.KEYS})
+                ag = a_geo.view(3, K, -1, 2).permute(1, 0, 2, 3)
+                at = a_topo.view(3, K, -1, 3).permute(1, 0, 2, 3)
                 added += self.replay.add(accepted.any(dim=1), S, NS, ag, at, R.float())
             tk = self._tick("replay", tk)
         # ---- end of the game step (:430-473, 642) ----

@@ -63,7 +63,7 @@ def _run(lib, device):
         np.testing.assert_allclose(outs[0][b].cpu().numpy(), want[:3], rtol=1e-9, atol=1e-11)
     # the stored designs reproduce their archived points (analysis of the archive = its points)
     chk = tm.BatchedTruss(eng.topo, B, device=device, lib=lib)
-    chk.x.copy_(eng.envP.x); chk.target.copy_(eng.envP.target); chk.env_params.copy_(eng.envP.env_params)
+    chk.x.copy_(eng.c_x); chk.target.copy_(eng.c_target); chk.env_params.copy_(eng.c_params)
     for m in range(int(n.max())):
         chk.y.copy_(eng.arch_y[:, m]); chk.sec.copy_(eng.arch_sec[:, m])
         chk.analyze()
