@@ -131,11 +131,12 @@ class multimodes_critic(nn.Module):
 
 def _clip_each(params, max_norm=1.0):
     """Keras `clipnorm`: every gradient tensor is clipped to L2 norm <= clipnorm on its own."""
-    for p in params:
-        if p.grad is not None:
-            n = p.grad.norm()
-            if n > max_norm:
-                p.grad.mul_(max_norm / (n + 1e-12))
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    # branch-free (no host synchronisation per tensor): the factor is exactly 1.0 where the norm is within bounds
+    norms = torch._foreach_norm(grads)
+    torch._foreach_mul_(grads, [torch.clamp(max_norm / (n + 1e-12), max=1.0) for n in norms])
 
 
 def _allreduce_grads(params, dist):
@@ -317,7 +318,7 @@ class MADDPG:
             _allreduce_grads(cp, self.dist)
             _clip_each(cp)
             ag.critic_opt.step()
-            ag.c_loss.append(float(loss.detach()))
+            ag.c_loss.append(loss.detach())          # stays on the device: no synchronisation inside the update
             # actor: maximise the own critic with all three actors re-evaluated (:617-629)
             preds = [a2.actor_model(self._actor_in(S)) for a2 in self.agents]
             q = ag.critic_model(S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
