@@ -162,3 +162,11 @@ def test_hip_kernels_use_no_scratch():
     # fallbacks for wide bands may park a register or two in the AGPR file (no memory traffic: scratch is 0).
     assert all(v == 0 for n, v in zip(names, spills) if "ELi2ELi" not in n), dict(zip(names, spills))
     assert all(v <= 4 for v in spills), dict(zip(names, spills))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_irregular_topologies_emulated(seed):
+    """not the reference's grid families: random bays / braces / supports (see parity_common.irregular_topology)"""
+    topo = pc.irregular_topology(seed)
+    env = pc.run_random_rollout(pc.emu_lib(), 0, 0, 5, 2, seed=seed, topo=topo)
+    assert int(env.status.sum()) == 0

@@ -153,3 +153,10 @@ def test_singular_design_is_flagged(lib):
     env.analyze()
     st = env.results()["status"]
     assert st[0] == 1 and st[1] == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_irregular_topologies(lib, seed):
+    topo = pc.irregular_topology(seed)
+    env = pc.run_random_rollout(lib, 0, 0, 40, 3, seed=seed, topo=topo)
+    assert int(env.status.sum()) == 0
