@@ -165,6 +165,22 @@ def main():
         a0.record(); e36.rollout(g36, a36, args.steps); a1.record(); torch.cuda.synchronize()
         extras["small_bridge_16n36e_env_steps_per_s"] = B * args.steps / (a0.elapsed_time(a1) * 1e-3)
         extras["small_bridge_lanes_per_env"] = t36.solver_info(lib)["lanes_per_env"]
+        # BASELINE configs[4] sizes: 128- and 256-node trusses (316 / 636 elements) on the 32- / 64-lane kernels
+        for nx_big, b_big in ((64, 2048), (128, 1024)):
+            tb = tm.TrussTopology.grid(nx_big)
+            bb = synthetic.random_batch(tb, b_big, seed=nx_big)
+            eb = tm.BatchedTruss(tb, b_big, device=dev, lib=lib)
+            eb.set_constants(bb["x"], bb["target"], bb["y_max"], bb["d_min"], bb["max_def"], bb["load_x"], bb["load_y"], bb["is_roof"])
+            eb.set_design(bb["y"], bb["sec"])
+            eb.analyze(set_normalisers=True)
+            gb, ab = synthetic.random_actions(2, b_big, tb.N, 5)
+            gb, ab = torch.tensor(gb, device=dev), torch.tensor(ab, device=dev)
+            eb.rollout(gb, ab, 10); torch.cuda.synchronize()
+            a0.record(); eb.rollout(gb, ab, 50); a1.record(); torch.cuda.synchronize()
+            us = a0.elapsed_time(a1) * 1e3 / 50
+            extras[f"large_{tb.N}n_{tb.E}e_{b_big}envs"] = {"us_per_step": us, "env_steps_per_s": b_big / (us * 1e-6),
+                                                               "lanes_per_env": tb.solver_info(lib)["lanes_per_env"],
+                                                               "nonpositive_pivots": int(eb.status.sum().item())}
 
     if rank == 0:
         per_step_bytes = algorithmic_bytes_per_env_step(topo.N, topo.E) * B

@@ -33,7 +33,8 @@ struct TbVariant {
 #define TRUSS_VARIANTS(X) X(16, 8, 1, 5)
 #else
 #define TRUSS_VARIANTS(X) \
-  X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20)
+  X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20) \
+  X(32, 8, 1, 10) X(64, 8, 1, 10) /* large trusses: up to 320 / 640 elements, 128 / 256 nodes (BASELINE config 5) */
 #endif
 static const TbVariant kVariants[] = {
 #define X(g, wl, r, e) {g, wl, r, e},
@@ -258,7 +259,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   if (pick < 0) {
     char buf[256];
     snprintf(buf, sizeof buf,
-             "no compiled kernel for half-bandwidth %d with %d elements (windows: 8, 16; lanes 4/8/16)", t->bw, E);
+             "no compiled kernel for half-bandwidth %d with %d elements (windows: 8, 16; up to 640 elements)", t->bw, E);
     delete t;
     return tb_fail(TRUSS_EUNSUPPORTED, buf);
   }

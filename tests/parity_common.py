@@ -172,7 +172,7 @@ def irregular_topology(seed):
     return tm.TrussTopology(np.array(conn, np.int32), res, g.top, g.pair)
 
 
-def run_random_rollout(lib, num_x, n_extra, B, n_steps, seed, symmetry=None, topo=None):
+def run_random_rollout(lib, num_x, n_extra, B, n_steps, seed, symmetry=None, topo=None, tight=1e-9):
     """Synthetic random-geometry batch, `n_steps` chained steps, native vs oracle every step."""
     irregular = topo is not None
     if irregular:
@@ -197,7 +197,7 @@ def run_random_rollout(lib, num_x, n_extra, B, n_steps, seed, symmetry=None, top
                  torch.tensor(coin, device=env.device))
         o = O.env_step(ot, batch["x"], y, sec, None, None, ag[s], at[s], coin.astype(np.float64), batch["target"], load,
                        batch["y_max"], batch["d_min"], batch["max_def"], batch["is_roof"], int_obj)
-        compare_step(env.results(), o, ot, zero_force=1e-9 if irregular else 0.0)
+        compare_step(env.results(), o, ot, tight=tight, zero_force=1e-9 if irregular else 0.0)
         y, sec = o["y"], o["sec"]
     return env
 

@@ -170,3 +170,15 @@ def test_irregular_topologies_emulated(seed):
     topo = pc.irregular_topology(seed)
     env = pc.run_random_rollout(pc.emu_lib(), 0, 0, 5, 2, seed=seed, topo=topo)
     assert int(env.status.sum()) == 0
+
+
+@pytest.mark.parametrize("num_x,tight", [(40, 1e-9), (64, 1e-9), (128, 1e-7)])
+def test_large_trusses_emulated(num_x, tight):
+    """BASELINE config 5 sizes: 80 / 128 / 256 nodes (196 / 316 / 636 elements, up to 508 DOF) on the 32- and
+    64-lane kernels.  The LU of the oracle and the LDL^T of the kernel drift apart with the condition number
+    (~ bays^4): 4e-9 at 256 nodes, far inside the 1e-5 budget."""
+    topo = tm.TrussTopology.grid(num_x)
+    info = topo.solver_info(pc.emu_lib())
+    assert info["lanes_per_env"] == (32 if num_x <= 64 else 64) and info["half_bandwidth"] == 7
+    env = pc.run_random_rollout(pc.emu_lib(), 0, 0, 2, 2, seed=num_x, topo=topo, tight=tight)
+    assert int(env.status.sum()) == 0

@@ -160,3 +160,10 @@ def test_irregular_topologies(lib, seed):
     topo = pc.irregular_topology(seed)
     env = pc.run_random_rollout(lib, 0, 0, 40, 3, seed=seed, topo=topo)
     assert int(env.status.sum()) == 0
+
+
+@pytest.mark.parametrize("num_x,tight", [(40, 1e-9), (64, 1e-9), (128, 1e-7)])
+def test_large_trusses(lib, num_x, tight):
+    topo = tm.TrussTopology.grid(num_x)
+    env = pc.run_random_rollout(lib, 0, 0, 24, 2, seed=num_x, topo=topo, tight=tight)
+    assert int(env.status.sum()) == 0
