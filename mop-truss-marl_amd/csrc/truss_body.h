@@ -219,9 +219,14 @@ struct StepLane {
   // before the first dependent LDS store: all loads go to registers first (clamped indices, no
   // control flow), then all stores.  Rows whose length is not a multiple of 4 words, or topologies
   // beyond the unrolled bounds, take the plain loop (stage_row_slow).
-  static constexpr int BIT = 8;                                // blob units (16 B) per lane, unrolled
-  static constexpr int NIT = (64 / 4 + G - 1) / G;             // N <= 64: float4 units of an [N] row per lane
-  static constexpr int EIT = (128 / 4 + G - 1) / G;            // E <= 128
+  static constexpr int BIT = 8;                                // blob units (16 B) per lane, unrolled (8 KB of tables)
+  static constexpr int BIT_BIG = 20;                           // ... for the large-truss variants (20 KB)
+  // float4 units of an [N] / [E] row per lane, from what the variant is built for: E <= G * EPL, and the
+  // grid families' N ~ 0.4 E (G * NPL nodes); at least the 64 nodes / 128 elements of the small variants
+  static constexpr int NCAP = (G * ((2 * EPL + 4) / 5) > 64) ? G * ((2 * EPL + 4) / 5) : 64;
+  static constexpr int ECAP = (G * EPL > 128) ? G * EPL : 128;
+  static constexpr int NIT = (NCAP / 4 + G - 1) / G;
+  static constexpr int EIT = (ECAP / 4 + G - 1) / G;
 
   TRUSS_HD void stage_row_slow(const void *src, void *dst, int nwords) const {
     const uint32_t *s1 = (const uint32_t *)src;
@@ -306,11 +311,12 @@ struct StepLane {
   TRUSS_HD void phase_stage(const TopoDev &T, const StepArgsDev &A) {
     const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
     const bool decode = !(A.flags & TB_NO_DECODE);
-    const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= 64 && T.E <= 128 && T.blob_bytes <= BIT * 64 * 16;
+    const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= NCAP && T.E <= ECAP && T.blob_bytes <= BIT_BIG * 64 * 16;
     heads = A.coin ? (A.coin[envc] != 0) : 0;
     if (fast) {
       if (T.blob_bytes <= 3 * 64 * 16) stage_fast<3>(T, A, decode);
-      else stage_fast<BIT>(T, A, decode);
+      else if (T.blob_bytes <= BIT * 64 * 16) stage_fast<BIT>(T, A, decode);
+      else stage_fast<BIT_BIG>(T, A, decode);
     } else {
       {
         const tb_u4 *s4 = (const tb_u4 *)T.blob;
@@ -985,7 +991,7 @@ struct StepLane {
     if (!active) return;
     const size_t bn = (size_t)env * T.N, be = (size_t)env * T.E;
     const bool mr = A.mu_out && T.has_pairs;
-    const bool fast = (T.N & 3) == 0 && (T.E & 15) == 0 && T.N <= 64 && T.E <= 128;
+    const bool fast = (T.N & 3) == 0 && (T.E & 15) == 0 && T.N <= NCAP && T.E <= ECAP;
     if (fast) {
       const int nn = T.N >> 2, ne = T.E >> 2, nc = T.E >> 4;
       tb_u4 vy[NIT], vs[EIT], vq[EIT], vr[EIT], vc[(EIT + 3) / 4], vd[2 * NIT], vu[NIT], vw[NIT];
