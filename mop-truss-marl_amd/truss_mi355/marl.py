@@ -26,6 +26,8 @@ Differences from the per-env loop, all forced by batching and documented here:
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 import torch
 
@@ -164,7 +166,6 @@ class BatchedMARL:
     def _tick(self, name, t0):
         if self.profile is None:
             return t0
-        import time
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         t1 = time.perf_counter()
@@ -238,7 +239,6 @@ class BatchedMARL:
         y0, sec0 = self.arch_y.clone(), self.arch_sec.clone()
         added = 0
         rsum = torch.zeros((B, 3), dtype=torch.float64, device=self.device)
-        import time
         tk = time.perf_counter()
         dev = self.device
         for m in range(int(n0.max().item())):
