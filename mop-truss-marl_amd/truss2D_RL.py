@@ -275,7 +275,8 @@ class MADDPG:
                     ag.target_critic_model(S + acts)
                 ag.update_init()
             if ag.critic_opt is None:
-                ag.critic_opt = torch.optim.Adam(ag.critic_model.parameters(), lr=ag.lr, eps=1e-7)
+                ag.critic_opt = torch.optim.Adam(ag.critic_model.parameters(), lr=ag.lr, eps=1e-7,
+                                                 capturable=self.device.type == "cuda")   # usable inside a hipGraph
 
     def train(self):
         batch_size = self.batch_size
@@ -332,7 +333,7 @@ class MADDPG:
                 p.grad = g
             _allreduce_grads(ap, self.dist)
             _clip_each(ap)
-            torch.optim.Adam(ap, lr=ag.lr * 0.1, eps=1e-7).step()       # a fresh optimiser every call
+            torch.optim.Adam(ap, lr=ag.lr * 0.1, eps=1e-7, capturable=self.device.type == "cuda").step()   # a fresh optimiser every call
 
     def sync_parameters(self, src=0):
         """Data-parallel start: every rank takes rank `src`'s actor / critic / target weights (one broadcast

@@ -161,6 +161,7 @@ class BatchedMARL:
         self.game_step = 1
         self._steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
         self._synced = False
+        self._tg, self.use_train_graph = None, True
         self.profile = None            # set to {} to accumulate synchronised wall time per segment (diagnostic)
 
     def _tick(self, name, t0):
@@ -231,6 +232,68 @@ class BatchedMARL:
                 geo.append(g.float().contiguous())
                 topo.append(t.float().contiguous())
         return geo, topo
+
+    # ---- the MADDPG update: eager, or (one GPU) replayed as a hipGraph ----
+    def _train(self, S, NS, A, R):
+        """The update is thousands of small kernels at batch 32 -- launch-bound.  On a single GPU it is captured
+        once into a hipGraph (static input buffers, capturable Adam) and replayed; with a process group (the
+        gradient all-reduce is a collective) or on the CPU backend it runs eagerly."""
+        d = getattr(self.rl, "dist", None)
+        multi = d is not None and d.is_initialized() and d.get_world_size() > 1
+        if self.device.type != "cuda" or multi or not self.use_train_graph:
+            return self.rl.train_on_batch(S, NS, A, R)
+        flat_in = list(S) + [t for ns in NS for t in ns] + [t for a in A for t in a] + [R]
+        if self._tg is None:
+            try:
+                bufs = [t.clone() for t in flat_in]
+                nS = len(S)
+
+                def unpack(b):
+                    s_ = b[:nS]
+                    ns_ = [b[nS * (1 + k): nS * (2 + k)] for k in range(3)]
+                    a_ = b[4 * nS: 4 * nS + 6]
+                    return s_, ns_, [(a_[0], a_[1]), (a_[2], a_[3]), (a_[4], a_[5])], b[4 * nS + 6]
+
+                # the warm-up runs real updates: weights and optimiser moments are put back afterwards (in place,
+                # the graph holds their addresses), so that training is what it would have been without capture
+                nets = [n for ag_ in self.rl.agents for n in (ag_.actor_model, ag_.critic_model, ag_.target_actor_model,
+                                                                ag_.target_critic_model)]
+                self.rl._ensure_ready(S, [A[0][0], A[0][1], A[1][0], A[1][1], A[2][0], A[2][1]])
+                snap = [[p.detach().clone() for p in n.parameters()] for n in nets]
+                had_state = [bool(ag_.critic_opt.state) for ag_ in self.rl.agents]
+                osnap = [{id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                          for p, st in ag_.critic_opt.state.items()} for ag_ in self.rl.agents]
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for _ in range(3):                                   # warm-up on the capture stream
+                        self.rl.train_on_batch(*unpack(bufs))
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self.rl.train_on_batch(*unpack(bufs))
+                with torch.no_grad():
+                    for n, sp in zip(nets, snap):
+                        for p, v in zip(n.parameters(), sp):
+                            p.copy_(v)
+                    for ag_, had, sn in zip(self.rl.agents, had_state, osnap):
+                        for p, st in ag_.critic_opt.state.items():
+                            for k, v in st.items():
+                                if torch.is_tensor(v):
+                                    v.copy_(sn[id(p)][k]) if had else v.zero_()
+                for ag_ in self.rl.agents:
+                    del ag_.c_loss[-4:]                                  # the warm-up / capture entries
+                self._tg = (g, bufs)
+            except Exception as e:                                       # capture is an optimisation, never a requirement
+                print(f"[marl] hipGraph capture of the MADDPG update failed ({type(e).__name__}: {e}); running eagerly")
+                self.use_train_graph = False
+                torch.cuda.synchronize(self.device)
+                return self.rl.train_on_batch(S, NS, A, R)
+        g, bufs = self._tg
+        for b, t in zip(bufs, flat_in):
+            b.copy_(t)
+        g.replay()
 
     # ---- one game step of every env (run() :198-705) ----
     def game_step_all(self, train: bool = True, explore: bool = True, train_iters: int = 1):
@@ -337,7 +400,7 @@ class BatchedMARL:
             for _ in range(train_iters):
                 S, NS, ag, at, R = self.replay.sample(self.batch_size, self.gen)
                 A = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
-                self.rl.train_on_batch(self._net_state(S), [self._net_state(ns) for ns in NS], A, R)
+                self._train(self._net_state(S), [self._net_state(ns) for ns in NS], A, R)
         tk = self._tick("train", tk)
         return dict(hv=hv["hv_front"], n_front=self.n.clone(), sum_distance=hv["metrics"][:, 3], reward=rsum, replay_added=added,
                     replay_size=self.replay.size)

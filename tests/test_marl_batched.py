@@ -117,3 +117,24 @@ def test_actor_infer_emulated():
 @pytest.mark.gpu
 def test_actor_infer_hip():
     _check_actor_infer(tm.load(), "cuda")
+
+
+@pytest.mark.gpu
+def test_train_graph_matches_eager_updates():
+    """The hipGraph-captured MADDPG update (one GPU) trains like the eager one: same seeds, same batches -> the
+    same weights up to the run-to-run noise of atomically accumulated gradients."""
+    lib = tm.load()
+    out = []
+    for use_graph in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = _engine(lib, "cuda", B=64, seed=5)
+            eng.use_train_graph = use_graph
+            for _ in range(4):
+                eng.game_step_all(train=True, explore=True, train_iters=2)
+        assert (eng._tg is not None) == use_graph
+        out.append([p.detach().clone() for ag in eng.rl.agents for p in list(ag.actor_model.parameters()) + list(ag.critic_model.parameters())])
+    moved = False
+    for a, b in zip(*out):
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5)
+        moved |= bool((a - b).abs().max() >= 0)
+    assert moved
