@@ -652,15 +652,24 @@ struct StepLane {
   }
 
   // post this lane's entries of pivot column k (kk = k mod W, compile-time after unrolling).  The pivot
-  // lane also publishes its right-hand side z_k: straight into the z vector, where the elimination of
-  // this step and, later, the back substitution find it (slot k held P_k, which the lane took when it
-  // adopted row k).  Nobody wants the other lanes' right-hand sides: their store goes to a per-lane trash
-  // slot (an LDS store costs the same under any exec mask, so the address is selected, not the lanes).
+  // lane's right-hand side z_k does not go through the LDS: it reaches the team by a DPP row broadcast in
+  // pivot_update (an LDS store costs ~40 cycles per wave-instruction when the four waves of the CU store
+  // together), and the lane keeps it for the back substitution: one store of the kept values per block of W
+  // pivots (factor_z_store) instead of one per pivot.
+  double zkeep[RPL];
   TRUSS_HD void pivot_write(const TopoDev &T, int k, int kk) {
 #pragma unroll
     for (int s = 0; s < RPL; ++s) Kt[k * W + gs + WL * s] = R[s][kk];
-    double *zp = (gs == kk % WL) ? Zt + k : ZRt + gs;
-    *zp = rhs[kk / WL];
+    bx = rhs[kk / WL];
+  }
+  // rows kb + (gs + WL s - c) mod W for a block that starts at window slot c (c = 0 for the clean blocks)
+  TRUSS_HD void factor_z_store(const TopoDev &T, int kb, int c, int cnt) {
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+      const int off = (gs + WL * s - c + W) % W;
+      double *zp = off < cnt ? Zt + kb + off : ZRt + gs;     // lanes without a pivot in this (partial) block: trash slot
+      *zp = zkeep[s];
+    }
   }
 
   TRUSS_HD void pivot_update(const TopoDev &T, int k, int kk) {
@@ -676,7 +685,8 @@ struct StepLane {
       col[2 * i] = v[0];
       col[2 * i + 1] = v[1];
     }
-    const double zk = Zt[k];
+    const double zk = tb_team_bcast(*this, kk % WL);     // the pivot lane's bx = its right-hand side z_k
+    if (gs == kk % WL) zkeep[kk / WL] = bx;
     const double d = col[kk];
     const double inv = tb_rcp(d);  // d <= 0 / NaN is detected after the loop (pivot_check), off the chain
 #pragma unroll
@@ -1108,6 +1118,7 @@ struct StepLane {
         PH(pivot_write(T, kb_ + kk_, kk_));                                         \
         PH_NS(pivot_update(T, kb_ + kk_, kk_));                                     \
       }                                                                             \
+      PH_NS(factor_z_store(T, kb_, 0, W_));                                         \
     }                                                                               \
     TRUSS_ST(13);                                                                   \
     /* Two-sided scheme: the rest of team A's/B's own pivots of this block, the merge at k = KA, and the \
@@ -1125,6 +1136,7 @@ struct StepLane {
             PH(pivot_write(T, kb_ + kk_, kk_));                                     \
             PH_NS(pivot_update(T, kb_ + kk_, kk_));                                 \
           }                                                                         \
+          if (c_ > 0) { PH_NS(factor_z_store(T, kb_, 0, c_)); }                     \
           PH(merge_post(T));                                                        \
           PH(merge_take(T));                                                        \
           TRUSS_UNROLL                                                              \
@@ -1133,6 +1145,7 @@ struct StepLane {
             PH(pivot_write(T, (T).KA + i_, (c_ + i_) % W_));                        \
             PH_NS(pivot_update(T, (T).KA + i_, (c_ + i_) % W_));                    \
           }                                                                         \
+          PH_NS(factor_z_store(T, (T).KA, c_, W_));                                 \
         }                                                                           \
       }                                                                             \
     } else if ((T).nteams == 2) { /* wide windows: W instances would not fit; guarded blocks instead */ \
@@ -1149,6 +1162,7 @@ struct StepLane {
             PH_NS(pivot_update(T, kb_ + kk_, kk_));                                 \
           }                                                                         \
         }                                                                           \
+        PH_NS(factor_z_store(T, kb_, 0, kend_ - kb_ < W_ ? kend_ - kb_ : W_));      \
       }                                                                             \
     }                                                                               \
     BAR();                                                                          \
