@@ -213,7 +213,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
                 # separate passes): profiles/r1/07_pmc_counters.json (valid for envs=4096, 32n/80e)
-                "traffic": 13446976 if (B == 4096 and topo.N == 32 and topo.E == 80) else None,
+                "traffic": 13468928 if (B == 4096 and topo.N == 32 and topo.E == 80) else None,
                 "kernel": "truss_step_kernel", "kernel_us": kern_s * 1e6,
                 "bytes_per_launch": per_step_bytes,
                 # the other two ceilings SURVEY §8d asks for (algorithmic banded flop count, 1e4 per env-step)
