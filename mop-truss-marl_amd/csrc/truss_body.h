@@ -1239,9 +1239,9 @@ struct StepLane {
   TRUSS_ST(7);                                                                      \
   PH(phase_post_nodes(T, A));                                                       \
   TRUSS_ST(8);                                                                      \
-  PH_NS(phase_store(T, A));                                                         \
-  TRUSS_ST(12);                                                                     \
   PH_NS(phase_finish(T, A));                                                        \
+  TRUSS_ST(12);                                                                     \
+  PH_NS(phase_store(T, A));                                                         \
   TRUSS_ST(9);
 
 // ================================================================================================

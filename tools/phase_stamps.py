@@ -58,7 +58,7 @@ def main():
         print(f"== {label} B={B}  {topo.solver_info(lib)['lanes_per_env']} lanes/env, total {acc.sum():.0f} cycles; stamped launch {us:.2f} us")
         for n, c in zip(NAMES, acc):
             print(f"   {n:22s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f} %")
-        for n, c in zip(["elements (pass 1+2)", "assemble_nodes", "scratch_init", "store rows", "finish",
+        for n, c in zip(["elements (pass 1+2)", "assemble_nodes", "scratch_init", "finish (point/obj/status)", "store rows",
                           "factor: clean blocks", "factor: merge blocks + check", "backsub: hand-over blocks", "backsub: clean blocks"], extra / 10):
             print(f"      - {n:20s} {c:9.0f} cyc")
 
