@@ -1258,6 +1258,7 @@ struct ObsArgsDev {
   const uint8_t *comp;
   const double *env_params;
   float *x_n, *A_s, *A_ts, *A_cs, *nxn, *nxe;
+  int32_t tile_rows;   // rows of the N x N matrices built per pass (tb_obs_tile_rows)
 };
 
 struct ObsLane {
@@ -1312,14 +1313,19 @@ struct ObsLane {
         o[11] = ratio >= 1.0f ? 1.0f : 0.0f;
       }
     }
+  }
+
+  // rows [r0, r0 + TR) of the three matrices: clear the tile
+  TRUSS_HD void phase_tile_clear(const TopoDev &T, const ObsArgsDev &A) {
     float *M = mats(T);
-    const int tot = 3 * T.N * T.N;
+    const int tot = 3 * A.tile_rows * T.N;
     for (int i = lane; i < tot; i += 64) M[i] = 0.0f;
   }
 
-  TRUSS_HD void phase_edges(const TopoDev &T, const ObsArgsDev &A) {
+  TRUSS_HD void phase_edges(const TopoDev &T, const ObsArgsDev &A, int r0) {
     const float *R = raw();
-    if (lane < 13) {  // column min / max for the normalisation (ENV:102)
+    const int TR = A.tile_rows;
+    if (r0 == 0 && lane < 13) {  // column min / max for the normalisation (ENV:102)
       float lo = R[lane], hi = R[lane];
       for (int n = 1; n < T.N; ++n) {
         float v = R[n * 13 + lane];
@@ -1330,7 +1336,7 @@ struct ObsLane {
       mx(T)[lane] = hi;
     }
     const size_t be = (size_t)env * T.E;
-    float *As = mats(T), *Ats = As + T.N * T.N, *Acs = Ats + T.N * T.N;
+    float *As = mats(T), *Ats = As + TR * T.N, *Acs = Ats + TR * T.N;
     const double *AR = TB_TAB(double, T.blob, T.f_area);
     const int16_t *CN = TB_TAB(int16_t, T.blob, T.f_conn);
     const double amax = AR[T.n_sections - 1];
@@ -1342,16 +1348,16 @@ struct ObsLane {
       const int cmp = A.comp[be + e];
       const float vs = (float)(area / amax);
       const float val = fminf(srv, 1.0f) * (srv > 1.0f ? 1.0f : 0.5f);
-      As[a * T.N + b] = vs;
-      As[b * T.N + a] = vs;
-      if (cmp == 0) {
-        Ats[a * T.N + b] = val;
-        Ats[b * T.N + a] = val;
-      } else {
-        Acs[a * T.N + b] = val;
-        Acs[b * T.N + a] = val;
+      float *Aq = cmp == 0 ? Ats : Acs;
+      if (a >= r0 && a < r0 + TR) {          // the element's two entries, each in the tile that holds its row
+        As[(a - r0) * T.N + b] = vs;
+        Aq[(a - r0) * T.N + b] = val;
       }
-      if (A.nxe) {
+      if (b >= r0 && b < r0 + TR) {
+        As[(b - r0) * T.N + a] = vs;
+        Aq[(b - r0) * T.N + a] = val;
+      }
+      if (A.nxe && r0 == 0) {
         float *o = A.nxe + (be + e) * 21;
         const double dx = (double)R[b * 13 + 0] - (double)R[a * 13 + 0];
         const double dy = (double)R[b * 13 + 1] - (double)R[a * 13 + 1];
@@ -1378,9 +1384,9 @@ struct ObsLane {
     }
   }
 
-  TRUSS_HD void phase_store(const TopoDev &T, const ObsArgsDev &A) {
+  TRUSS_HD void phase_store(const TopoDev &T, const ObsArgsDev &A, int r0) {
     const float *R = raw();
-    if (A.x_n) {
+    if (A.x_n && r0 == 0) {
       float *o = A.x_n + (size_t)env * T.N * 13;
       const float *lo = mn(T), *hi = mx(T);
       for (int i = lane; i < T.N * 13; i += 64) {
@@ -1388,14 +1394,15 @@ struct ObsLane {
         TB_STREAM_STORE(&o[i], (R[i] - lo[c]) / (hi[c] - lo[c] + 1e-6f));
       }
     }
-    const int nn = T.N * T.N;
+    const int rows = (r0 + A.tile_rows <= T.N ? A.tile_rows : T.N - r0);
+    const int nn = rows * T.N;                       // floats of this tile
     const float *M = mats(T);
     float *outs[3] = {A.A_s, A.A_ts, A.A_cs};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       if (!outs[m]) continue;
-      float *o = outs[m] + (size_t)env * nn;
-      const float *src = M + m * nn;
+      float *o = outs[m] + (size_t)env * T.N * T.N + (size_t)r0 * T.N;
+      const float *src = M + m * A.tile_rows * T.N;
       if ((nn & 3) == 0) {
         const tb_u4 *s4 = (const tb_u4 *)src;
         tb_u4 *o4 = (tb_u4 *)o;
@@ -1407,7 +1414,10 @@ struct ObsLane {
   }
 };
 
-#define TRUSS_OBS_SCHEDULE(PH, PH_NS, T, A) \
-  PH(phase_nodes(T, A));                    \
-  PH(phase_edges(T, A));                    \
-  PH_NS(phase_store(T, A));
+#define TRUSS_OBS_SCHEDULE(PH, PH_NS, T, A)                              \
+  PH(phase_nodes(T, A));                                                 \
+  for (int r0_ = 0; r0_ < (T).N; r0_ += (A).tile_rows) {                 \
+    PH(phase_tile_clear(T, A));                                          \
+    PH(phase_edges(T, A, r0_));                                          \
+    PH(phase_store(T, A, r0_));                                          \
+  }

@@ -43,8 +43,17 @@ static const TbVariant kVariants[] = {
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
+// observation kernel LDS: raw[N][13] | mn[13] | mx[13] | (pad to 16) | three [TR][N] matrix tiles.
+// TR = rows per tile: all N rows when the three N x N matrices fit (one pass, 32-node trusses: 12 KB); large
+// trusses are written in row tiles (256 nodes: 3 x 256 KB would not fit any CU).
+static inline int tb_obs_tile_rows(int N) {
+  const size_t budget = 96 * 1024;
+  size_t tr = budget / ((size_t)3 * N * 4);
+  if (tr > (size_t)N) tr = (size_t)N;
+  return tr < 1 ? 1 : (int)tr;
+}
 static inline size_t tb_obs_lds_bytes(int N) {
-  return ((((size_t)(N * 13 + 26) * 4 + 15) & ~(size_t)15) + (size_t)3 * N * N * 4 + 15) & ~(size_t)15;
+  return ((((size_t)(N * 13 + 26) * 4 + 15) & ~(size_t)15) + (size_t)3 * tb_obs_tile_rows(N) * N * 4 + 15) & ~(size_t)15;
 }
 
 struct truss_topo {
@@ -644,6 +653,7 @@ extern "C" int truss_obs(const truss_topo_t *t, const truss_obs_args_t *a, void 
       !a->env_params)
     return tb_fail(TRUSS_EINVAL, "a required device pointer is NULL");
   if (tb_obs_lds_bytes(t->N) > 160 * 1024) return tb_fail(TRUSS_EUNSUPPORTED, "N too large for the observation kernel");
+  // (with row tiles that is N > ~3000)
   ObsArgsDev D;
   D.B = a->n_envs;
   D.flags = a->flags;
@@ -664,5 +674,6 @@ extern "C" int truss_obs(const truss_topo_t *t, const truss_obs_args_t *a, void 
   D.A_cs = a->A_n_cs;
   D.nxn = a->nN_x_n;
   D.nxe = a->nN_x_e;
+  D.tile_rows = tb_obs_tile_rows(t->N);
   return tb_launch_obs(t, D, stream);
 }

@@ -182,3 +182,9 @@ def test_large_trusses_emulated(num_x, tight):
     assert info["lanes_per_env"] == (32 if num_x <= 64 else 64) and info["half_bandwidth"] == 7
     env = pc.run_random_rollout(pc.emu_lib(), 0, 0, 2, 2, seed=num_x, topo=topo, tight=tight)
     assert int(env.status.sum()) == 0
+
+
+@pytest.mark.parametrize("num_x", [64, 128])
+def test_observation_tensors_large_emulated(num_x):
+    """128 / 256 nodes: the three N x N matrices are written in row tiles (2 resp. 8 passes)"""
+    pc.run_obs_random(pc.emu_lib(), num_x, 0, 2, seed=num_x)

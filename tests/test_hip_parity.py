@@ -167,3 +167,8 @@ def test_large_trusses(lib, num_x, tight):
     topo = tm.TrussTopology.grid(num_x)
     env = pc.run_random_rollout(lib, 0, 0, 24, 2, seed=num_x, topo=topo, tight=tight)
     assert int(env.status.sum()) == 0
+
+
+@pytest.mark.parametrize("num_x", [64, 128])
+def test_observation_tensors_large(lib, num_x):
+    pc.run_obs_random(lib, num_x, 0, 6, seed=num_x)
