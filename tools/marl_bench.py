@@ -24,15 +24,15 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     train = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
-    dev = "cuda"
-    topo = tm.TrussTopology.grid(8)                       # test/01_small_roof: 16 nodes, 36 elements
+    nx = int(sys.argv[4]) if len(sys.argv) > 4 else 8     # bays + 1; 8 = test/01_small_roof (16 nodes, 36 elements);
+    dev = "cuda"                                          # 16 / 32 / 64 / 128 = the size classes of BASELINE configs[4]
+    topo = tm.TrussTopology.grid(nx)
     rl = RL.MADDPG(M.lr, M.ep, M.epd, M.gamma, M.a_nn, M.c_nn, 100, M.num_agents, M.num_action, M.mu, M.theta, M.sigma, device=dev)
     eng = marl.BatchedMARL(topo, B, rl, max_front=20, device=dev, replay_capacity=32768, batch_size=32)
-    nx = 8
     x = np.tile(np.arange(nx) * 5.0, 2)
-    tar = np.concatenate([np.zeros(nx), [4, 3, 2.5, 2, 2, 2.5, 3, 4]])
+    tar = np.concatenate([np.zeros(nx), 2.0 + 2.0 * np.abs(np.linspace(-1, 1, nx))])
     y0 = np.concatenate([np.zeros(nx), np.full(nx, 8.0)]).astype(np.float32)
-    eng.reset(x[None].repeat(B, 0), tar[None].repeat(B, 0), 8.0, 0.3, 0.035, 0.0, -120000.0, 1.0, y0[None].repeat(B, 0),
+    eng.reset(x[None].repeat(B, 0), tar[None].repeat(B, 0), 8.0, 0.3, 0.001 * 5.0 * (nx - 1), 0.0, -120000.0 * 8 / nx, 1.0, y0[None].repeat(B, 0),
               np.full((B, topo.E), 4, np.int32))
     with contextlib.redirect_stdout(io.StringIO()):
         eng.game_step_all(train=train)                    # warm-up (lazy layers, first launches)
@@ -46,7 +46,7 @@ def main():
             st = eng.game_step_all(train=train)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"config": "small_roof 16n/36e, MADDPG GCN agents in the loop", "envs": B, "game_steps": steps, "train": train,
+    print(json.dumps({"config": f"roof truss {topo.N}n/{topo.E}e, MADDPG GCN agents in the loop", "envs": B, "game_steps": steps, "train": train,
                       "env_steps": eng.env_steps - e0, "seconds": dt, "env_steps_per_s": (eng.env_steps - e0) / dt,
                       "mean_front": float(st["n_front"].float().mean()), "mean_hv": float(st["hv"].mean()),
                       "replay_size": st["replay_size"], "profile_s": eng.profile}))
