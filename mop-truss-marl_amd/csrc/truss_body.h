@@ -706,7 +706,8 @@ struct StepLane {
     if (gs == kk % WL) {
       const int sp = kk / WL;
 #pragma unroll
-      for (int j = 0; j < W; ++j) R[sp][j] = fr[sp][j];
+      for (int j = 0; j < W; ++j)
+        if (j != kk) R[sp][j] = fr[sp][j];   // slot kk already holds the new row's diagonal: it came in as ecol
       rhs[sp] = frhs[sp];
     }
   }
