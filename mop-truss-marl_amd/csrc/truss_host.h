@@ -49,6 +49,11 @@ static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 static inline int tb_obs_tile_rows(int N) {
   const size_t budget = 96 * 1024;
   size_t tr = budget / ((size_t)3 * N * 4);
+  if (tr >= (size_t)N) {
+    // everything would fit in one pass -- but two passes of half the rows halve the LDS of a workgroup, and
+    // the launch then fits the CUs in one round (4096 envs x 13.8 KB did not: 26.8 -> 24.9 us at 32 nodes)
+    tr = N >= 16 ? (size_t)(((N + 1) / 2 + 3) & ~3) : (size_t)N;
+  }
   if (tr > (size_t)N) tr = (size_t)N;
   return tr < 1 ? 1 : (int)tr;
 }
