@@ -1320,7 +1320,13 @@ struct ObsLane {
   TRUSS_HD void phase_tile_clear(const TopoDev &T, const ObsArgsDev &A) {
     float *M = mats(T);
     const int tot = 3 * A.tile_rows * T.N;
-    for (int i = lane; i < tot; i += 64) M[i] = 0.0f;
+    if ((tot & 3) == 0) {                       // 16-byte stores (mats() is 16-byte aligned)
+      tb_u4 *M4 = (tb_u4 *)M;
+      const tb_u4 z = {0u, 0u, 0u, 0u};
+      for (int i = lane; i < tot / 4; i += 64) M4[i] = z;
+    } else {
+      for (int i = lane; i < tot; i += 64) M[i] = 0.0f;
+    }
   }
 
   TRUSS_HD void phase_edges(const TopoDev &T, const ObsArgsDev &A, int r0) {
