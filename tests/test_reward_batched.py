@@ -130,3 +130,36 @@ def test_difference_reward_emulated():
 @pytest.mark.gpu
 def test_difference_reward_hip():
     _check_reward(tm.load(), "cuda")
+
+
+def _check_edge_cases(lib, device):
+    """empty sets, all-infeasible sets, a single (1, 1) point, the full 64 rows"""
+    P = 64
+    pts = np.zeros((4, P, 4))
+    n = np.array([0, 3, 1, 64], np.int32)
+    pts[1, :3] = [[0.5, 0.5, 1.2, 0.1], [0.4, 0.6, 0.2, 1.5], [0.3, 0.7, 2.0, 2.0]]       # nothing feasible
+    pts[2, 0] = [1.0, 1.0, 0.5, 0.5]
+    rng = np.random.default_rng(9)
+    x = np.sort(rng.uniform(0.1, 0.9, 64)); y = np.sort(rng.uniform(0.1, 0.9, 64))[::-1]
+    pts[3] = np.stack([x, y, np.full(64, 0.3), np.full(64, 0.3)], axis=1)
+    out = RW.front_hv(torch.tensor(pts, device=device), torch.tensor(n, device=device), None, 0, lib)
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    assert list(o["n_front"]) == [0, 0, 1, 64]
+    assert o["hv_front"][0] == 0 and o["hv_all"][0] == 0 and np.all(o["front_idx"][0] == -1)
+    assert o["hv_front"][1] == 0 and np.all(o["front_idx"][1] == -1)
+    assert abs(o["hv_all"][1] - U.union_rectangles_fastest([list(r) for r in pts[1, :3]], +1, -1)) < 1e-12
+    assert o["hv_front"][2] == 0 and o["hv_all"][2] == 0            # the (1, 1) special case (utils.py:279-281)
+    assert list(o["front_idx"][3]) == list(range(64))
+    fr = U.simple_cull_final([list(r) for r in pts[3]])
+    np.testing.assert_allclose(o["metrics"][3], fr[1:6], rtol=1e-11)
+    assert abs(o["hv_front"][3] - U.union_rectangles_fastest(fr[0], +1, -1)) < 1e-12
+    assert np.all(np.isfinite(o["metrics"]))
+
+
+def test_front_edge_cases_emulated():
+    _check_edge_cases(pc.emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_front_edge_cases_hip():
+    _check_edge_cases(tm.load(), "cuda")
