@@ -168,7 +168,7 @@ class BatchedTruss:
         # an RL loop passes the same buffers every step: validated argument blocks are kept per buffer set
         key = (self.cur, flags, a_geo.data_ptr(), a_topo.data_ptr(), coin.data_ptr(),
                0 if max_up_in is None else max_up_in.data_ptr(), 0 if max_down_in is None else max_down_in.data_ptr(),
-               a_geo.shape, a_topo.shape, B)
+               a_geo.shape, a_topo.shape, a_geo.dtype, a_topo.dtype, a_geo.is_contiguous(), a_topo.is_contiguous(), B)
         a = self._step_cache.get(key)
         if a is None:
             self._chk(a_geo, (B, N, 2), torch.float32, "a_geo")
