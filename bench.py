@@ -148,9 +148,21 @@ def main():
         a1.record(); torch.cuda.synchronize()
         so_us = a0.elapsed_time(a1) * 1e3 / 100
         b_obs = algorithmic_bytes_per_env_step(topo.N, topo.E) + 4 * (13 * topo.N + 5 * topo.N ** 2 + 12 * topo.N + 21 * topo.E)
+        extras["step_then_obs_two_launches_us"] = so_us
+        # the same through TRUSS_F_EMIT_OBS: the step's own launch writes the observation tensors
+        ob = env.obs_buffers()
+        env.step(ag0, at0, obs=ob); torch.cuda.synchronize()
+        a0.record()
+        for _ in range(200):
+            env.step(ag0, at0, obs=ob)
+        a1.record(); torch.cuda.synchronize()
+        so_us = a0.elapsed_time(a1) * 1e3 / 200
+        moved = algorithmic_bytes_per_env_step(topo.N, topo.E) + obs_bytes
+        extras["fused_obs_one_launch"] = bool(env.fused_obs)
         extras["step_plus_obs_us"] = so_us
         extras["step_plus_obs_env_steps_per_s"] = B / (so_us * 1e-6)
         extras["step_plus_obs_frac_of_hbm_peak_B_obs"] = B * b_obs / (so_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        extras["step_plus_obs_frac_of_hbm_peak_bytes_moved"] = B * moved / (so_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         # BASELINE configs[1] topology: small bridge, 16 nodes / 36 elements (reference-exact grid)
         t36 = tm.TrussTopology.grid(8)
         b36 = synthetic.random_batch(t36, B, seed=7)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TRUSS_ABI_VERSION 2
+#define TRUSS_ABI_VERSION 3
 
 #define TRUSS_OK 0
 #define TRUSS_EINVAL (-1)       /* bad argument (NULL, size mismatch, pair table not an involution ...) */
@@ -39,6 +39,10 @@ extern "C" {
 #define TRUSS_F_NO_DECODE 0x1u     /* analysis only: y_out = y_in, sec_out = sec_in (reset path) */
 #define TRUSS_F_CLAMP_INPLACE 0x2u /* write the clamped actions back into a_geo / a_topo
                                       (truss2D_ENV.py:376-388 mutates the caller's arrays) */
+#define TRUSS_F_EMIT_OBS 0x4u      /* also write the observation tensors of the NEW design (x_n ... nN_x_e below):
+                                      _game_modify builds them in the same call (truss2D_ENV.py:497-500).  One
+                                      launch where the topology allows it (truss_topo_fused_obs), otherwise the
+                                      observation kernel is queued behind the step on the same stream */
 
 /* columns of env_params[B][TRUSS_NPARAM] (float64) */
 #define TRUSS_NPARAM 8
@@ -99,6 +103,10 @@ int truss_topo_dofs(const truss_topo_t *t, int32_t *nsc, int32_t *ttnsc);
 int truss_topo_solver_info(const truss_topo_t *t, int32_t *perm, int32_t *half_bandwidth,
                            int32_t *lanes_per_env, int32_t *rows_per_lane);
 
+/* 1 when truss_step writes the observation tensors from the step's own launch for this topology
+ * (TRUSS_F_EMIT_OBS), 0 when it queues the observation kernel behind it.  Same results either way. */
+int truss_topo_fused_obs(const truss_topo_t *t);
+
 /* ---- the batched environment step ----------------------------------------------------------
  * One Game_research04._game_modify(set_node, set_element, nC_e, actions) per env
  * (truss2D_ENV.py:370-525): clamp -> _set_model -> geometry move -> supports/round -> section
@@ -144,6 +152,15 @@ typedef struct truss_step_args {
   double *reactions; /* [B][2N-ndof] or NULL: Model.r[ndof:] (FEM_2Dtruss.py:393-411) */
   int32_t *status;  /* [B] or NULL: 0 ok, 1 = non-positive pivot (K not SPD: the reference would
                        raise numpy.linalg.LinAlgError from FEM_2Dtruss.py:337 or return garbage) */
+
+  /* observation tensors of the new design, written with TRUSS_F_EMIT_OBS (needs sec_out and max_up_out /
+   * max_down_out); same contents and layouts as truss_obs_args_t below; any of them may be NULL */
+  float *x_n;     /* [B][N][13]  state_data          truss2D_ENV.py:50-102 */
+  float *A_s;     /* [B][N][N]                       :86-87 */
+  float *A_n_ts;  /* [B][N][N]                       :92-97 */
+  float *A_n_cs;  /* [B][N][N]                       :98-100 */
+  float *nN_x_n;  /* [B][N][12]  state_data_not_norm :134-146 */
+  float *nN_x_e;  /* [B][E][21]                      :148-169 */
 } truss_step_args_t;
 
 int truss_step(const truss_topo_t *t, const truss_step_args_t *args, void *stream);

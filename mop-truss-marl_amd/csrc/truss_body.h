@@ -51,13 +51,20 @@
 // flags (mirror include/truss_mi355.h)
 #define TB_NO_DECODE 0x1u
 #define TB_CLAMP_INPLACE 0x2u
+#define TB_EMIT_OBS 0x4u
 
 // 16-byte unit of the HBM<->LDS copies: a native vector type (kept in VGPRs; a struct here ended up in scratch)
 #if defined(__clang__)
 typedef uint32_t tb_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t tb_u2 __attribute__((ext_vector_type(2)));
+typedef float tb_f4 __attribute__((ext_vector_type(4)));
+typedef float tb_f2 __attribute__((ext_vector_type(2)));
 typedef double tb_d2 __attribute__((ext_vector_type(2)));
 #else
 typedef uint32_t tb_u4 __attribute__((vector_size(16)));
+typedef uint32_t tb_u2 __attribute__((vector_size(8)));
+typedef float tb_f4 __attribute__((vector_size(16)));
+typedef float tb_f2 __attribute__((vector_size(8)));
 typedef double tb_d2 __attribute__((vector_size(16)));
 #endif
 // 16-byte LDS row access (ds_read_b128 / ds_write_b128): band rows are 16-byte aligned
@@ -96,12 +103,37 @@ struct TopoDev {
   int32_t f_area;      // double [n_sections] area in m^2
   int32_t f_isr;       // double [n_sections] 1 / (area * long_stress)
   int32_t f_adj8;      // int16 [N][8]   elements incident to each node, padded with E (a zero slot)
+  int32_t f_areaf;     // float [n_sections] (float)area                          (nN_x_e column 1, ENV:150)
+  int32_t f_vsf;       // float [n_sections] (float)(area / largest area)         (A_s, ENV:86-87)
   double e_mod, long_stress;
   // LDS layout of the step kernel: [blob copy][env 0][env 1]...; o_* are byte offsets inside one env
   int32_t o_env0, env_stride;
   int32_t o_kb, o_zs, o_xsol, o_red, o_rbuf, o_par, o_y, o_x, o_tg, o_geo, o_tac, o_sec, o_ev, o_zring, o_mrg;
   // output staging rows inside the (dead) band region, each 16-byte aligned
   int32_t so_q0, so_sr, so_disp, so_mu, so_md, so_comp;
+  // ---- fused observation emission (TB_EMIT_OBS, see "observation emission" in StepLane) ----
+  // emit_ok: this topology/variant can write the observation tensors from the step kernel itself.
+  // chunk = 16 output bytes; lane g of an env handles chunks g, g + G, ... of every tensor (= "iterations").  Tables
+  // are padded by the host to the variant's compile-time iteration counts, entries past the end of a tensor repeat
+  // its last chunk (the store address is clamped the same way: a duplicate rewrites the same bytes).
+  //   etab (global memory -> registers):   entries of iterations (2p, 2p+1) of a lane are adjacent (one 16-byte load)
+  //     et_xn / et_nxn : [pair][G][2] x 4 uint16  float offsets (from the env's LDS base) of the chunk's 4 values
+  //     et_mat         : [pair][G][2] x 4 uint16  N x N matrices, row-major chunks of 4 cells: the element joining
+  //                      (row, col), or E = none
+  //   f_tnxe (LDS, behind the tables every kernel stages: `blob_bytes` of an EMIT launch includes it):
+  //     [iter][G] x 4 uint16 float offsets, as et_xn
+  int32_t emit_ok;
+  const char *etab;
+  int32_t o_flag;   // LDS byte offset of the workgroup's progress word (compute wave -> streaming wave)
+  int32_t et_xn, et_nxn, et_mat, f_tnxe;
+  int32_t nc_xn, nc_nxn, nc_nxe, nc_mat;   // chunks per env
+  // feature bank: float offsets (from the env's LDS base) of the arrays the tables point into; they live in
+  // bytes of the env that are dead by the time they are written (band, solver scratch, action rows)
+  int32_t b_const;                                            // [0] = 0, [1] = 1, [2] = 1 / (1 + 1e-6f)
+  int32_t b_nload, b_nt9, b_nady, b_nvge;                     // per node: raw features the step does not hold as rows
+  int32_t b_xn[9];                                            // per node: normalised columns 0 1 4 7 8 9 10 11 12 of x_n
+  int32_t b_esec, b_earea, b_elen, b_etens, b_ecomp, b_eviol; // per element: nN_x_e columns 0 1 2 3 4 6 (post_elements)
+  int32_t b_ev2;                                              // per element (+1 zero record): float2 (A_n_ts, A_n_cs) values
 };
 
 #define TB_TAB(type, base, off) ((const type *)((base) + (off)))
@@ -124,6 +156,7 @@ struct StepArgsDev {
   float *point, *obj;
   double *disp64, *q064, *energy, *react;
   int32_t *status;
+  float *x_n, *A_s, *A_ts, *A_cs, *nxn, *nxe;   // observation tensors of the new design (TB_EMIT_OBS), each may be NULL
 };
 
 #define TRUSS_NRED 6  // vol, dt, con1, con2, energy, (spare)
@@ -137,10 +170,13 @@ TRUSS_HD float tb_round2(float v) { return rintf(v * 100.0f) / 100.0f; }
 // one row per lane the second group of WL lanes is a second TEAM that eliminates the reversed system from
 // the other end (two-sided scheme, see the solver section); any further lanes mirror lane g % WL through the
 // solver (same registers, same LDS addresses) and only contribute in the per-node / per-element phases.
-template <int G, int WL, int RPL, int EPL>
+// EMIT instantiations additionally write the observation tensors of the new design (state_data +
+// state_data_not_norm, truss2D_ENV.py:40-193, 497-500) from the same launch: "observation emission" below.
+template <int G, int WL, int RPL, int EPL, bool EMIT = false>
 struct StepLane {
   static constexpr int W = WL * RPL;
   static constexpr int WL_ = WL;
+  static constexpr int G_ = G;
   static constexpr int NPL = (2 * EPL + 4) / 5;   // nodes per lane unrolled (two-row grid trusses: N ~ 0.4 E)
   static constexpr int EPB = 64 / G;  // envs per wave
   static constexpr int NDEG = 8;      // unrolled node-degree bound of the diagonal gather
@@ -533,6 +569,7 @@ struct StepLane {
       ec[i] = c;
       es[i] = s;
       ei[i] = ISR[sc];
+      if constexpr (EMIT) el[i] = (float)len;   // nN_x_e column 2 (ENV:151)
       if (e < T.E) p_vol += (double)(float)(Aa * len);  // all_v[i] is a float32 store (ENV:508)
       const double kc = k * c, ks = k * s;
       kcc[i] = kc * c;
@@ -1078,18 +1115,327 @@ struct StepLane {
       if (A.status) A.status[env] = sum != 0.0 ? 1 : 0;
     }
   }
+
+  // ==== observation emission (EMIT) ==============================================================
+  // state_data / state_data_not_norm (truss2D_ENV.py:40-193) of the design this step analyses, written by the
+  // step's own wave: every input of the observation is in LDS or registers at some point of the step, so the
+  // second launch, its re-read of the result rows and the host hop between the two launches go away.
+  //
+  // All index arithmetic is done once per topology on the host (truss_host.h, tb_build_emit): an output tensor
+  // is a flat run of 16-byte chunks per env, chunk q is written by lane q % G, and a table gives, for each of
+  // the chunk's four floats, the offset of its source inside the env's LDS region -- either a row the step
+  // holds anyway (x, y, staged q0 / max_up / max_down) or an entry of the FEATURE BANK (derived per-node /
+  // per-element values, placed in bytes that are dead by the time they are written).  The kernel side is then:
+  // fill the bank, gather, stream.  Every store instruction writes whole aligned 256-byte runs per env (a first
+  // version stored the all-zero chunks of the N x N matrices separately from the chunks holding an edge: partial
+  // writes of the same lines at different times, 71.7 us per step instead of 54.7 us for two launches).
+  //
+  // WHO streams.  The launch is one compute wave per SIMD; a store burst issued by that wave blocks it (in-order
+  // issue, a short store queue) for as long as HBM takes to drain the burst, so stores issued early do not overlap
+  // with its later compute: step time = compute + bytes / bandwidth (35.0 us with A_s streamed before the solver
+  // and A_n_ts / A_n_cs before the nodal phases; 40.9 us with everything at the end).  EMIT workgroups therefore
+  // have a SECOND wavefront, the streaming wave: it loads the tables, sleeps on a progress word in LDS and does
+  // all the gather + store work of the tensors whose inputs the compute wave has announced:
+  //   1  new sections final (after sizing)        -> A_s   (area ratios: needs the sections only; ENV:86-87)
+  //   2  element part of the bank written         -> A_n_ts, A_n_cs
+  //   3  node part of the bank written (the end)  -> nN_x_e, nN_x_n, x_n
+  // (publishing the raw node features separately, so that nN_x_e / nN_x_n start before the normalisation: +0.8 us)
+  // The compute wave never waits for the streaming wave and never stores an observation byte; of the observation work
+  // it keeps the bank: derived element / node values it has in registers or one LDS read away (the streaming wave
+  // shares its SIMD with another workgroup's compute wave and gets the issue slots that one leaves: arithmetic is
+  // slow there, waiting for HBM is free), with the column normalisation of x_n as its very last act.  Every table
+  // lookup, gather and store is the streaming wave's.  The two communicate through the
+  // result rows the step stages in LDS anyway (q0, stress ratios, flags, displacements, move ranges), the design rows
+  // and the bank; everything the streaming wave reads stays untouched until the workgroup ends, and the bank lives
+  // in bytes nobody else touches any more when it is written (dead band, action rows, solver scratch except the
+  // reactions).  Measured at 4096 envs: bank by the compute wave 32.4-33.4 us, bank by the streaming wave 35.8 us.  Its table loads precede all its stores: gfx9 has ONE vmcnt for
+  // loads and stores, in issue order, and a load issued behind a store can only be waited for together with it.
+  static constexpr int NF = G * NPL, EF = G * EPL;   // nodes / elements covered by the unrolled per-lane loops
+  static constexpr int IX = EMIT ? (13 * NF / 4 + G - 1) / G : 1;     // chunks per lane: x_n
+  static constexpr int IN_ = EMIT ? (12 * NF / 4 + G - 1) / G : 1;    //                  nN_x_n
+  static constexpr int IE = EMIT ? (21 * EF / 4 + G - 1) / G : 1;     //                  nN_x_e
+  static constexpr int IM = EMIT ? (NF * NF / 4 + G - 1) / G : 1;     //                  each N x N matrix
+  static constexpr int NDYN = 9;                                      // x_n columns 0 1 4 7 8 9 10 11 12 vary per env
+  static constexpr int KB = 8;                                        // chunks gathered back to back before their stores
+  tb_u2 etx[IX], etn[IN_], etm[IM];
+  float el[EMIT ? EPL : 1];           // element lengths (phase_elements)
+  float nfe[EMIT ? NPL : 1][NDYN];    // raw dynamic columns of the lane's nodes
+  float pmn[NDYN], pmx[NDYN];         // partial column min / max over the lane's nodes
+
+  template <int IT>
+  TRUSS_HD void tab_load(const char *base, tb_u2 (&v)[IT]) const {
+    const tb_u4 *t = (const tb_u4 *)base;
+#pragma unroll
+    for (int p = 0; p < (IT + 1) / 2; ++p) {
+      const tb_u4 w = t[p * G + g];
+      const tb_u2 lo = {w[0], w[1]}, hi = {w[2], w[3]};
+      v[2 * p] = lo;
+      if (2 * p + 1 < IT) v[2 * p + 1] = hi;
+    }
+  }
+  TRUSS_HD void emit_tables_load(const TopoDev &T) {   // streaming wave, before its first store
+    if constexpr (EMIT) {
+      tab_load<IM>(T.etab + T.et_mat, etm);
+      tab_load<IX>(T.etab + T.et_xn, etx);
+      tab_load<IN_>(T.etab + T.et_nxn, etn);
+    }
+  }
+  // store address of iteration i (a lane past the end of the tensor redoes its last chunk)
+  TRUSS_HD int chunk_of(int i, int nc) const {
+    const int q = g + G * i;
+    return q < nc ? q : nc - 1;
+  }
+
+  // ---- A_s (ENV:86-87): area / largest area on both cells of every element; needs the new sections only:
+  // cell -> element (table) -> section (the env's section row) -> ratio (topology table)
+  TRUSS_HD void obs_emit_as(const TopoDev &T, const StepArgsDev &A) {
+    if constexpr (EMIT) {
+      if (!active || !A.A_s) return;
+      const int32_t *S = secsh(T);
+      const float *VF = TB_TAB(float, TB, T.f_vsf);
+      tb_f4 *o4 = (tb_f4 *)A.A_s + (size_t)env * ((size_t)T.N * T.N / 4);
+      const int E = T.E;
+#pragma unroll
+      for (int b0 = 0; b0 < IM; b0 += KB) {
+        if (b0 * G < T.nc_mat) {             // wave-uniform, once per batch
+          int sc[KB][4];
+#pragma unroll
+          for (int k = 0; k < KB; ++k)
+            if (b0 + k < IM) {
+              const tb_u2 t = etm[b0 + k];
+              const int e0 = t[0] & 0xffffu, e1 = t[0] >> 16, e2 = t[1] & 0xffffu, e3 = t[1] >> 16;
+              sc[k][0] = e0 < E ? S[e0] : -1;
+              sc[k][1] = e1 < E ? S[e1] : -1;
+              sc[k][2] = e2 < E ? S[e2] : -1;
+              sc[k][3] = e3 < E ? S[e3] : -1;
+            }
+#pragma unroll
+          for (int k = 0; k < KB; ++k)
+            if (b0 + k < IM) {
+              const tb_f4 v = {sc[k][0] >= 0 ? VF[sc[k][0]] : 0.0f, sc[k][1] >= 0 ? VF[sc[k][1]] : 0.0f,
+                               sc[k][2] >= 0 ? VF[sc[k][2]] : 0.0f, sc[k][3] >= 0 ? VF[sc[k][3]] : 0.0f};
+              TB_STREAM_STORE(&o4[chunk_of(b0 + k, T.nc_mat)], v);
+            }
+        }
+      }
+    }
+  }
+  // ---- A_n_ts / A_n_cs (ENV:89-100): one (tension, compression) record per cell, two chunks stored
+  TRUSS_HD void obs_emit_tc(const TopoDev &T, const StepArgsDev &A) {
+    if constexpr (EMIT) {
+      if (!active || (!A.A_ts && !A.A_cs)) return;
+      const tb_f2 *R = (const tb_f2 *)((const float *)L + T.b_ev2);
+      const size_t nn4 = (size_t)T.N * T.N / 4;
+      tb_f4 *pt = (tb_f4 *)A.A_ts + env * nn4, *pc = (tb_f4 *)A.A_cs + env * nn4;
+#pragma unroll
+      for (int b0 = 0; b0 < IM; b0 += KB) {
+        if (b0 * G < T.nc_mat) {
+          tb_f2 r[KB][4];
+#pragma unroll
+          for (int k = 0; k < KB; ++k)
+            if (b0 + k < IM) {
+              const tb_u2 t = etm[b0 + k];
+              r[k][0] = R[t[0] & 0xffffu];
+              r[k][1] = R[t[0] >> 16];
+              r[k][2] = R[t[1] & 0xffffu];
+              r[k][3] = R[t[1] >> 16];
+            }
+#pragma unroll
+          for (int k = 0; k < KB; ++k)
+            if (b0 + k < IM) {
+              const int q = chunk_of(b0 + k, T.nc_mat);
+              const tb_f4 vt = {r[k][0][0], r[k][1][0], r[k][2][0], r[k][3][0]};
+              const tb_f4 vc = {r[k][0][1], r[k][1][1], r[k][2][1], r[k][3][1]};
+              if (A.A_ts) TB_STREAM_STORE(&pt[q], vt);
+              if (A.A_cs) TB_STREAM_STORE(&pc[q], vc);
+            }
+        }
+      }
+    }
+  }
+
+  // ---- bank, elements (compute wave, behind post_elements): nN_x_e columns 0-4, 6 (ENV:148-156) and the edge values of
+  // A_n_ts / A_n_cs (ENV:92-100) from the rows the step staged
+  TRUSS_HD void obs_elements_bank(const TopoDev &T, const StepArgsDev &A) {
+    if constexpr (EMIT) {
+      float *Lf = (float *)L;
+      const float *SR = osr(T);
+      const int32_t *S = secsh(T);
+      const uint8_t *CP = ocomp(T);
+      const float *AF = TB_TAB(float, TB, T.f_areaf);
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        const int e = g + G * i;
+        const int ee = e < T.E ? e : T.E - 1;   // a clamped duplicate rewrites element E-1's values
+        const int sc = S[ee];
+        const float srv = SR[ee];
+        const bool cmp = CP[ee] != 0;
+        const float val = fminf(srv, 1.0f) * (srv > 1.0f ? 1.0f : 0.5f);
+        Lf[T.b_esec + ee] = (float)sc;
+        Lf[T.b_earea + ee] = AF[sc];
+        Lf[T.b_elen + ee] = el[i];
+        Lf[T.b_etens + ee] = cmp ? 0.0f : 1.0f;
+        Lf[T.b_ecomp + ee] = cmp ? 1.0f : 0.0f;
+        Lf[T.b_eviol + ee] = srv > 1.0f ? 1.0f : 0.0f;
+        const tb_f2 rec = {cmp ? 0.0f : val, cmp ? val : 0.0f};
+        ((tb_f2 *)(Lf + T.b_ev2))[ee] = rec;
+      }
+      if (g == 0) {
+        const tb_f2 z = {0.0f, 0.0f};
+        ((tb_f2 *)(Lf + T.b_ev2))[T.E] = z;                             // the "no edge" record
+        Lf[T.b_const + 0] = 0.0f;
+        Lf[T.b_const + 1] = 1.0f;
+        Lf[T.b_const + 2] = (1.0f - 0.0f) / (1.0f - 0.0f + 1e-6f);   // a 0/1 column with both values present
+      }
+    }
+  }
+
+  // ---- bank, nodes A (compute wave, behind the step's own stores): raw features of the lane's nodes (ENV:50-100, 134-146) ----
+  TRUSS_HD void obs_nodes_raw(const TopoDev &T, const StepArgsDev &A) {
+    if constexpr (EMIT) {
+      load_params(T);
+      float *Lf = (float *)L;
+      const float *Y = ysh(T), *X = xsh(T), *TG = tgsh(T), *DS = odisp(T), *MU = omu(T), *MD = omd(T);
+      const uint8_t *NFL = t_nflags(T);
+      const float maxdef32 = (float)max_def;
+      const int lbit = is_roof ? TF_LOAD_ROOF : TF_LOAD_BRIDGE;
+#pragma unroll
+      for (int c = 0; c < NDYN; ++c) {
+        pmn[c] = INFINITY;
+        pmx[c] = -INFINITY;
+      }
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = g + G * i;
+        const int nc = n < T.N ? n : T.N - 1;   // a clamped duplicate rewrites node N-1's values
+        const int fl = NFL[nc];
+        const float y = Y[nc];
+        float *f = nfe[i];
+        f[0] = X[nc];
+        f[1] = y;
+        f[2] = (fl & lbit) ? 1.0f : 0.0f;
+        f[3] = MU[nc];
+        f[4] = MD[nc];
+        f[5] = (fl & TF_TOP) ? TG[nc] / (y + 1e-6f) : 0.0f;
+        f[6] = fabsf(DS[2 * nc + 1]);
+        const float ratio = f[6] / maxdef32;
+        f[7] = fminf(ratio, 1.0f) * (ratio > 1.0f ? 1.0f : 0.5f);
+        f[8] = ratio > 1.0f ? 1.0f : 0.0f;
+        Lf[T.b_nload + nc] = f[2];
+        Lf[T.b_nt9 + nc] = f[5];
+        Lf[T.b_nady + nc] = f[6];
+        Lf[T.b_nvge + nc] = ratio >= 1.0f ? 1.0f : 0.0f;
+        if (n < T.N) {
+#pragma unroll
+          for (int c = 0; c < NDYN; ++c) {
+            pmn[c] = fminf(pmn[c], f[c]);
+            pmx[c] = fmaxf(pmx[c], f[c]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- bank, nodes B (compute wave, last): column min / max over the env's lanes, normalised columns (ENV:102) ----
+  TRUSS_HD void obs_bank_fill(const TopoDev &T, const StepArgsDev &A) {
+    if constexpr (EMIT) {
+      float *Lf = (float *)L;
+#pragma unroll
+      for (int c = 0; c < NDYN; ++c) {
+        const float lo = tb_group_min(*this, c), hi = tb_group_max(*this, c);
+        // (v - lo) / (hi - lo + 1e-6f) (ENV:102) as a product with the reciprocal of the column's denominator (one
+        // reciprocal per column instead of one IEEE division per value): <= 1 ulp from the quotient
+        const float inv = tb_rcpf(hi - lo + 1e-6f);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          const int n = g + G * i;
+          Lf[T.b_xn[c] + (n < T.N ? n : T.N - 1)] = (nfe[i][c] - lo) * inv;
+        }
+      }
+    }
+  }
+
+  TRUSS_HD tb_f4 gather4(const float *Lf, const tb_u2 t) const {
+    const tb_f4 v = {Lf[t[0] & 0xffffu], Lf[t[0] >> 16], Lf[t[1] & 0xffffu], Lf[t[1] >> 16]};
+    return v;
+  }
+  // rows of one tensor: KB chunks' gathers are issued back to back, then their stores (a chunk at a time the
+  // wave paid one LDS round trip per 16 output bytes)
+  template <int IT>
+  TRUSS_HD void emit_rows(float *out, size_t row_floats, int nc, const tb_u2 (&tab)[IT]) const {
+    if (!out) return;
+    const float *Lf = (const float *)L;
+    tb_f4 *o4 = (tb_f4 *)(out + (size_t)env * row_floats);
+#pragma unroll
+    for (int b0 = 0; b0 < IT; b0 += KB) {
+      if (b0 * G < nc) {
+        tb_f4 v[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (b0 + k < IT) v[k] = gather4(Lf, tab[b0 + k]);
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (b0 + k < IT) TB_STREAM_STORE(&o4[chunk_of(b0 + k, nc)], v[k]);
+      }
+    }
+  }
+  // nN_x_e: the same with its table in LDS
+  TRUSS_HD void emit_nxe(const TopoDev &T, const StepArgsDev &A) const {
+    if (!A.nxe) return;
+    const float *Lf = (const float *)L;
+    const tb_u2 *tab = TB_TAB(tb_u2, TB, T.f_tnxe);
+    tb_f4 *o4 = (tb_f4 *)(A.nxe + (size_t)env * 21 * T.E);
+#pragma unroll
+    for (int b0 = 0; b0 < IE; b0 += KB) {
+      if (b0 * G < T.nc_nxe) {
+        tb_u2 t[KB];
+        tb_f4 v[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (b0 + k < IE) t[k] = tab[(b0 + k) * G + g];
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (b0 + k < IE) v[k] = gather4(Lf, t[k]);
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (b0 + k < IE) TB_STREAM_STORE(&o4[chunk_of(b0 + k, T.nc_nxe)], v[k]);
+      }
+    }
+  }
+  TRUSS_HD void obs_emit_raw_rows(const TopoDev &T, const StepArgsDev &A) {
+    if constexpr (EMIT) {
+      if (!active) return;
+      emit_nxe(T, A);
+      emit_rows<IN_>(A.nxn, (size_t)12 * T.N, T.nc_nxn, etn);
+    }
+  }
+  TRUSS_HD void obs_emit_xn(const TopoDev &T, const StepArgsDev &A) {
+    if constexpr (EMIT) {
+      if (!active) return;
+      emit_rows<IX>(A.x_n, (size_t)13 * T.N, T.nc_xn, etx);
+    }
+  }
 };
 
 // The phase schedule, shared by the HIP kernel and the emulator.
+//   EMIT_POINT(k)  (EMIT kernels) everything segment k of the streaming wave reads is final.  HIP: the compute wave
+//               publishes progress k and goes on; emulator: runs TRUSS_STREAM_SEGk here
 //   PH(call)    run `ln.call` for every lane, then a workgroup barrier
 //   PH_NS(call) run it without a trailing barrier (no lane reads what another lane writes in it
 //               before the next barrier)
 //   BAR()       explicit barrier
-// W_ must be a constexpr in scope; TRUSS_UNROLL expands to the unroll pragma on the GPU so that the
+// W_ and EMIT_ must be constexprs in scope; TRUSS_UNROLL expands to the unroll pragma on the GPU so that the
 // register-window indices (kk_) are compile-time constants.
 #ifndef TRUSS_ST
 #define TRUSS_ST(i)  // phase time stamp hook (diagnostic build only)
 #endif
+// The streaming wave's work per progress value (PH as above).  HIP: the second wavefront of an EMIT workgroup runs
+// segment k once the compute wave has published k; emulator: EMIT_POINT(k, ...) runs segment k in place.
+#define TRUSS_STREAM_SEG1(PH, T, A) PH(obs_emit_as(T, A));
+#define TRUSS_STREAM_SEG2(PH, T, A) PH(obs_emit_tc(T, A));
+#define TRUSS_STREAM_SEG3(PH, T, A) \
+  PH(obs_emit_raw_rows(T, A));      \
+  PH(obs_emit_xn(T, A));
 #define TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)                                   \
   TRUSS_ST(0);                                                                      \
   PH(phase_stage(T, A));                                                            \
@@ -1099,6 +1445,7 @@ struct StepLane {
   TRUSS_ST(2);                                                                      \
   PH(phase_sizing(T, A));                                                           \
   if ((T).n_sym_elems > 0 && !((A).flags & TB_NO_DECODE)) { PH(phase_sym_elems(T)); } \
+  if (EMIT_) { EMIT_POINT(1); } /* compile-time; the sections are final */           \
   TRUSS_ST(3);                                                                      \
   PH(phase_elements(T, A));                                                         \
   TRUSS_ST(10);                                                                     \
@@ -1237,12 +1584,22 @@ struct StepLane {
   BAR();                                                                            \
   TRUSS_ST(6);                                                                      \
   PH(phase_post_elements(T, A));                                                    \
+  if (EMIT_) {                                                                      \
+    PH(obs_elements_bank(T, A));                                                    \
+    EMIT_POINT(2);                                                                  \
+  }                                                                                 \
   TRUSS_ST(7);                                                                      \
   PH(phase_post_nodes(T, A));                                                       \
   TRUSS_ST(8);                                                                      \
   PH_NS(phase_finish(T, A));                                                        \
   TRUSS_ST(12);                                                                     \
   PH_NS(phase_store(T, A));                                                         \
+  if (EMIT_) {                                                                      \
+    BAR(); /* the node part of the bank reuses solver scratch the nodal phases have just read */ \
+    PH(obs_nodes_raw(T, A));                                                        \
+    PH(obs_bank_fill(T, A));                                                        \
+    EMIT_POINT(3);                                                                  \
+  }                                                                                 \
   TRUSS_ST(9);
 
 // ================================================================================================

@@ -7,8 +7,10 @@
 // the algorithmic bytes of the step (DESIGN.md "bytes per env-step").
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <type_traits>
 
 #include "../../include/truss_mi355.h"
 
@@ -70,10 +72,16 @@ __device__ __forceinline__ double tb_rcp(double d) {
   return r;
 }
 
+// 1/d in float32: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float tb_rcpf(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+
 #ifdef TRUSS_STAMPS
 // Diagnostic build only (make diag): lane 0 of one mid-grid workgroup records s_memtime at the phase
 // boundaries into a buffer nothing else reads.  Never enabled in libtruss_mi355.so.
-__device__ unsigned long long g_truss_stamps[16];
+__device__ unsigned long long g_truss_stamps[24];
 // g_truss_span: every workgroup's first and last stamp as (shader clock, 100 MHz wall clock): spread of
 // the workgroups over the launch, effective shader frequency (tools/span.py).
 __device__ unsigned long long g_truss_span[4096][4];
@@ -81,7 +89,7 @@ __device__ unsigned long long g_truss_span[4096][4];
   do {                                                               \
     __builtin_amdgcn_sched_barrier(0);                               \
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_truss_stamps[i] = clock64(); \
-    if (threadIdx.x == 0 && ((i) == 0 || (i) == 9) && blockIdx.x < 4096) {              \
+    if (threadIdx.x == 0 && ((i) == 0 || (i) == (EMIT_ ? 18 : 9)) && blockIdx.x < 4096) {              \
       g_truss_span[blockIdx.x][(i) == 0 ? 0 : 2] = clock64();                            \
       g_truss_span[blockIdx.x][(i) == 0 ? 1 : 3] = wall_clock64();                       \
     }                                                                \
@@ -98,16 +106,82 @@ __device__ __forceinline__ double tb_rsqrt(double x) {
   return r;
 }
 
+// min / max over the G lanes of an env (all lanes get the result), DPP only: xor 1, xor 2 inside a quad,
+// row_half_mirror (other quad of the 8), row_mirror (other half of the 16-lane row); beyond a row: ds_bpermute
+template <int G, bool MAX>
+__device__ __forceinline__ float tb_group_reduce(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  if constexpr (G >= 2) v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+  if constexpr (G >= 4) v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  if constexpr (G >= 16) v = op(v, dpp(v, std::integral_constant<int, 0x140>{})); // row_mirror
+  if constexpr (G >= 32) v = op(v, __shfl_xor(v, 16));
+  if constexpr (G >= 64) v = op(v, __shfl_xor(v, 32));
+  return v;
+}
+template <class LN>
+__device__ __forceinline__ float tb_group_min(LN &ln, int c) { return tb_group_reduce<LN::G_, false>(ln.pmn[c]); }
+template <class LN>
+__device__ __forceinline__ float tb_group_max(LN &ln, int c) { return tb_group_reduce<LN::G_, true>(ln.pmx[c]); }
+
 #include "truss_body.h"
 
-template <int G, int WL, int RPL, int EPL>
-__global__ __launch_bounds__(64) void truss_step_kernel(const TopoDev T, const StepArgsDev A) {
+// Progress word of an EMIT workgroup (LDS): the compute wave raises it, the streaming wave sleeps on it.
+// LDS operations of one wave execute in issue order, so the plain store of the word is ordered behind every
+// LDS store the compute wave issued before it, and the streaming wave's reads behind its read of the word;
+// the wavefront-scope fences only pin the compiler.
+__device__ __forceinline__ void tb_publish(char *lds, int o_flag, int k) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) *(volatile int *)(lds + o_flag) = k;
+}
+// false = gave up (the compute wave never got there: a fault is being reported elsewhere); the bound keeps the
+// grid draining in every case
+__device__ __forceinline__ bool tb_await(char *lds, int o_flag, int k) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    const int v = *(volatile int *)(lds + o_flag);
+    if (__builtin_amdgcn_readfirstlane(v) >= k) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return false;
+}
+
+template <int G, int WL, int RPL, int EPL, bool EMIT>
+__global__ __launch_bounds__(EMIT ? 128 : 64) void truss_step_kernel(const TopoDev T, const StepArgsDev A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  StepLane<G, WL, RPL, EPL> ln;
-  ln.init(threadIdx.x, blockIdx.x, T, A, smem);
-  constexpr int W_ = StepLane<G, WL, RPL, EPL>::W;
-  // The workgroup IS one wavefront: its LDS instructions execute in issue order, so a later ds_read
-  // sees an earlier ds_write of any lane without waiting for it.  A wavefront-scope fence plus
+  StepLane<G, WL, RPL, EPL, EMIT> ln;
+  ln.init(threadIdx.x & 63, blockIdx.x, T, A, smem);
+  constexpr int W_ = StepLane<G, WL, RPL, EPL, EMIT>::W;
+  constexpr bool EMIT_ = EMIT;
+  if constexpr (EMIT) {
+    // two wavefronts: 0 computes the step, 1 streams the observation tensors (truss_body.h, "WHO streams")
+    if (threadIdx.x == 0) *(volatile int *)(smem + T.o_flag) = 0;
+    __syncthreads();   // the only workgroup barrier of the kernel: the progress word starts at 0
+    if (threadIdx.x >= 64) {
+#define SPH(call) \
+  ln.call;        \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+  __builtin_amdgcn_wave_barrier();                        \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+      ln.emit_tables_load(T);   // ahead of every store of this wave in the vmcnt order
+      if (!tb_await(smem, T.o_flag, 1)) return;
+      TRUSS_STREAM_SEG1(SPH, T, A)
+      if (!tb_await(smem, T.o_flag, 2)) return;
+      TRUSS_STREAM_SEG2(SPH, T, A)
+      if (!tb_await(smem, T.o_flag, 3)) return;
+      TRUSS_STREAM_SEG3(SPH, T, A)
+#undef SPH
+      return;
+    }
+  }
+  // The compute wave has the env's LDS bytes to itself: its LDS instructions execute in issue order, so a later
+  // ds_read sees an earlier ds_write of any lane without waiting for it.  A wavefront-scope fence plus
   // wave_barrier keeps the compiler from reordering across a phase boundary and emits no s_waitcnt /
   // s_barrier (a __syncthreads() here costs a full LDS round trip per pivot of the factorisation).
 #define TB_WAVE_SYNC()                                    \
@@ -121,10 +195,12 @@ __global__ __launch_bounds__(64) void truss_step_kernel(const TopoDev T, const S
   TB_WAVE_SYNC()
 #define PH_NS(call) ln.call
 #define BAR() TB_WAVE_SYNC()
+#define EMIT_POINT(k) tb_publish(smem, T.o_flag, k)
   TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
 #undef PH
 #undef PH_NS
 #undef BAR
+#undef EMIT_POINT
 }
 
 __global__ __launch_bounds__(64) void truss_obs_kernel(const TopoDev T, const ObsArgsDev A) {
@@ -295,48 +371,61 @@ static void tb_dev_free(void *p) { (void)hipFree(p); }
 static bool tb_dev_upload(void *dst, const void *src, size_t n) {
   return hipMemcpy(dst, src, n, hipMemcpyHostToDevice) == hipSuccess;
 }
-static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *stream);
+static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *stream);
 static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream);
 
 #include "truss_host.h"
 
-static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)truss_obs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+// Dynamic LDS beyond 64 KiB needs an opt-in per kernel AND per device; one flag per (kernel, device), set once
+// (the C ABI promises thread safety per stream: relaxed atomics, a repeated hipFuncSetAttribute is harmless).
+static constexpr int TB_MAX_DEVICES = 64;
+struct TbLdsOptIn {
+  std::atomic<bool> done[TB_MAX_DEVICES];
+  int ensure(const void *kern) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TB_MAX_DEVICES) return tb_fail(TRUSS_EHIP, "hipGetDevice failed");
+    if (done[dev].load(std::memory_order_acquire)) return TRUSS_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return tb_fail(TRUSS_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr_set = true;
+    done[dev].store(true, std::memory_order_release);
+    return TRUSS_OK;
   }
+};
+
+static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream) {
+  static TbLdsOptIn optin;
+  if (int rc = optin.ensure((const void *)truss_obs_kernel)) return rc;
   hipLaunchKernelGGL(truss_obs_kernel, dim3((unsigned)A.B), dim3(64), tb_obs_lds_bytes(t->N), (hipStream_t)stream, t->dev, A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("obs kernel launch failed: ") + hipGetErrorString(e));
   return TRUSS_OK;
 }
 
-template <int G, int WL, int RPL, int EPL>
+template <int G, int WL, int RPL, int EPL, bool EMIT>
 static int hip_run(const truss_topo *t, const StepArgsDev &A, hipStream_t st) {
-  static bool attr_set = false;
-  static size_t attr_bytes = 0;
-  auto kern = truss_step_kernel<G, WL, RPL, EPL>;
-  if (!attr_set || t->lds_bytes > attr_bytes) {  // dynamic LDS beyond 64 KiB needs the opt-in
-    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return tb_fail(TRUSS_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr_set = true;
-    attr_bytes = 160 * 1024;
-  }
+  static TbLdsOptIn optin;
+  auto kern = truss_step_kernel<G, WL, RPL, EPL, EMIT>;
+  if (int rc = optin.ensure((const void *)kern)) return rc;
   constexpr int EPB = 64 / G;
   const unsigned grid = (unsigned)((A.B + EPB - 1) / EPB);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), t->lds_bytes, st, t->dev, A);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(EMIT ? 128 : 64), EMIT ? t->lds_bytes_emit : t->lds_bytes, st, EMIT ? t->dev_emit : t->dev, A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return TRUSS_OK;
 }
 
-static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *stream) {
+static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *stream) {
   const TbVariant &v = kVariants[t->variant];
   hipStream_t st = (hipStream_t)stream;
+  if (emit) {
 #define X(g, wl, r, e) \
-  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) return hip_run<g, wl, r, e>(t, A, st);
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) return hip_run<g, wl, r, e, true>(t, A, st);
+    TRUSS_EMIT_VARIANTS(X)
+#undef X
+    return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled with the observation writer");
+  }
+#define X(g, wl, r, e) \
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) return hip_run<g, wl, r, e, false>(t, A, st);
   TRUSS_VARIANTS(X)
 #undef X
   return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled");
@@ -345,6 +434,9 @@ static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *strea
 #ifdef TRUSS_STAMPS
 extern "C" int truss_debug_span(unsigned long long *out, int nblocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_truss_span), (size_t)nblocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+extern "C" int truss_debug_stamps24(unsigned long long *out24) {
+  return hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_truss_stamps), 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 extern "C" int truss_debug_stamps(unsigned long long *out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_truss_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;

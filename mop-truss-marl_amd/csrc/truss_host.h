@@ -4,7 +4,8 @@
 //     TRUSS_BACKEND_NAME                           "hip" | "emu"
 //     void *tb_dev_alloc(size_t);  void tb_dev_free(void *);
 //     bool tb_dev_upload(void *dst, const void *src, size_t bytes);
-//     int  tb_launch_step(const truss_topo *, const StepArgsDev &, void *stream);
+//     int  tb_launch_step(const truss_topo *, const StepArgsDev &, bool emit, void *stream);
+//          (emit: the instantiation that also writes the observation tensors; only asked for when dev.emit_ok)
 //     int  tb_launch_obs(const truss_topo *, const ObsArgsDev &, void *stream);
 // truss_hip.hip implements them with the HIP runtime; tests/emu/truss_emu.cpp with malloc and the
 // CPU lane emulator.
@@ -36,6 +37,19 @@ struct TbVariant {
   X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20) \
   X(32, 8, 1, 10) X(64, 8, 1, 10) /* large trusses: up to 320 / 640 elements, 128 / 256 nodes (BASELINE config 5) */
 #endif
+// variants that are also compiled with the fused observation emission (StepLane<..., EMIT = true>)
+#ifdef TRUSS_ONLY_DEFAULT_VARIANT
+#define TRUSS_EMIT_VARIANTS(X) X(16, 8, 1, 5)
+#else
+#define TRUSS_EMIT_VARIANTS(X) X(8, 8, 1, 5) X(16, 8, 1, 3) X(16, 8, 1, 5)
+#endif
+static bool tb_variant_emits(int G, int WL, int RPL, int EPL) {
+#define X(g, wl, r, e) \
+  if (G == g && WL == wl && RPL == r && EPL == e) return true;
+  TRUSS_EMIT_VARIANTS(X)
+#undef X
+  return false;
+}
 static const TbVariant kVariants[] = {
 #define X(g, wl, r, e) {g, wl, r, e},
     TRUSS_VARIANTS(X)
@@ -61,15 +75,155 @@ static inline size_t tb_obs_lds_bytes(int N) {
   return ((((size_t)(N * 13 + 26) * 4 + 15) & ~(size_t)15) + (size_t)3 * tb_obs_tile_rows(N) * N * 4 + 15) & ~(size_t)15;
 }
 
+static int tb_env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+template <typename T>
+static size_t tb_push(std::vector<char> &blob, const std::vector<T> &v) {
+  size_t off = (blob.size() + 15) & ~size_t(15);
+  blob.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+  return off;
+}
+
 struct truss_topo {
   int N = 0, E = 0, NP = 0, ndof = 0, n_pad = 0, n_rest = 0, bw = 0;
   int G = 0, WL = 0, RPL = 0, EPL = 0, W = 0, variant = -1;
   std::vector<int32_t> nsc, ttnsc, perm;
-  TopoDev dev{};
+  TopoDev dev{};        // what a plain step launch gets
+  TopoDev dev_emit{};   // ... an EMIT launch: the staged tables include the nN_x_e gather table (larger blob_bytes / o_env0)
+  size_t lds_bytes_emit = 0;
   void *blob = nullptr;
+  void *etab = nullptr;   // emission tables of the fused observation writer (TopoDev::etab)
   size_t lds_bytes = 0;
   int n_sections = 0;
 };
+
+// ---- fused observation emission: feature bank placement + gather tables (TopoDev "emit" fields) -------------
+// Dead byte ranges of one env's LDS region, by the time from which the streaming wave may overwrite them:
+//   early = once the member results are staged (behind phase_post_elements): band behind the staging rows and the
+//           objective partials; action rows
+//   late  = behind phase_post_nodes: solver scratch (z vectors, solution vector, trash slots -- not the reactions
+//           and the objective partials, so that the placement does not depend on where phase_finish runs)
+// Builds the register tables (t->etab, uploaded here) and appends the LDS-resident nN_x_e table to `blob`.
+// Returns false when the topology is outside what the fused writer covers; truss_step then runs the observation
+// kernel as a second launch.
+struct TbFrag {
+  size_t lo, hi;
+};
+static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res, const uint8_t *top,
+                          std::vector<TbFrag> early, std::vector<TbFrag> late, std::vector<char> &blob) {
+  TopoDev &D = t->dev;
+  const int N = t->N, E = t->E, G = t->G;
+  D.emit_ok = 0;
+  if (!tb_variant_emits(t->G, t->WL, t->RPL, t->EPL) || tb_env_int("TRUSS_NO_FUSED_OBS", 0)) return false;
+  const int NPL = (2 * t->EPL + 4) / 5, NF = G * NPL, EF = G * t->EPL;
+  if ((N & 3) || (E & 3) || N > NF || E > EF || !D.has_pairs) return false;
+  // the kernel's compile-time iteration counts (StepLane::IX ...)
+  const int IX = (13 * NF / 4 + G - 1) / G, IN_ = (12 * NF / 4 + G - 1) / G, IE = (21 * EF / 4 + G - 1) / G,
+            IM = (NF * NF / 4 + G - 1) / G;
+  // first-fit placement of the bank arrays (sizes in floats; all multiples of 4 but the constants, placed last)
+  struct Arr {
+    int32_t *dst;
+    int n;
+  };
+  auto place = [](std::vector<Arr> arrs, std::vector<TbFrag> &frags) {
+    for (auto &f : frags) f.lo = (f.lo + 15) & ~size_t(15);
+    for (const Arr &a : arrs) {
+      bool placed = false;
+      for (auto &f : frags)
+        if (f.lo + (size_t)a.n * 4 <= f.hi) {
+          *a.dst = (int32_t)(f.lo / 4);
+          f.lo += ((size_t)a.n * 4 + 15) & ~size_t(15);
+          placed = true;
+          break;
+        }
+      if (!placed) return false;
+    }
+    return true;
+  };
+  if (!place({{&D.b_ev2, 2 * (E + 1)}, {&D.b_esec, E}, {&D.b_earea, E}, {&D.b_elen, E}, {&D.b_etens, E}, {&D.b_ecomp, E}, {&D.b_eviol, E},
+              {&D.b_const, 3}},   // the constants are written with the element part (progress 2)
+             early))
+    return false;
+  for (const TbFrag &f : early) late.push_back(f);   // what the element arrays left over
+  std::vector<Arr> nodes = {{&D.b_nload, N}, {&D.b_nt9, N}, {&D.b_nady, N}, {&D.b_nvge, N}};
+  for (int c = 0; c < 9; ++c) nodes.push_back({&D.b_xn[c], N});
+  if (!place(nodes, late)) return false;
+  if (D.env_stride / 4 > 65535 || E + 1 > 65535) return false;
+  const int ZERO = D.b_const, ONE = D.b_const + 1, C1 = D.b_const + 2;
+  const int fX = D.o_x / 4, fY = D.o_y / 4, fMU = (D.o_kb + D.so_mu) / 4, fMD = (D.o_kb + D.so_md) / 4,
+            fQ0 = (D.o_kb + D.so_q0) / 4;
+  // 0/1 columns of x_n (res_x, res_y, top, 1 - top): min-max normalisation of a constant column gives 0
+  auto flag = [&](int n, int c) -> int { return c == 2 ? res[2 * n] != 0 : c == 3 ? res[2 * n + 1] != 0 : c == 5 ? top[n] != 0 : top[n] == 0; };
+  bool any0[13] = {}, any1[13] = {};
+  for (int n = 0; n < N; ++n)
+    for (int c : {2, 3, 5, 6}) (flag(n, c) ? any1[c] : any0[c]) = true;
+  const int dyn_of[13] = {0, 1, -1, -1, 2, -1, -1, 3, 4, 5, 6, 7, 8};
+  std::vector<uint16_t> txn, tnxn, tnxe, tmat;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < 13; ++c)
+      txn.push_back((uint16_t)(dyn_of[c] >= 0 ? D.b_xn[dyn_of[c]] + n : (flag(n, c) && any0[c] ? C1 : ZERO)));
+  for (int n = 0; n < N; ++n) {
+    const int src[12] = {fX + n, fY + n, res[2 * n] ? ONE : ZERO, res[2 * n + 1] ? ONE : ZERO, D.b_nload + n, top[n] ? ONE : ZERO,
+                         top[n] ? ZERO : ONE, fMU + n, fMD + n, D.b_nt9 + n, D.b_nady + n, D.b_nvge + n};
+    for (int c = 0; c < 12; ++c) tnxn.push_back((uint16_t)src[c]);
+  }
+  for (int e = 0; e < E; ++e) {
+    const int own[7] = {D.b_esec + e, D.b_earea + e, D.b_elen + e, D.b_etens + e, D.b_ecomp + e, fQ0 + e, D.b_eviol + e};
+    for (int c = 0; c < 7; ++c) tnxe.push_back((uint16_t)own[c]);
+    for (int q = 0; q < 2; ++q) {
+      const int n = conn[2 * e + q];
+      const int nd[7] = {fX + n, fY + n, res[2 * n] ? ONE : ZERO, res[2 * n + 1] ? ONE : ZERO, D.b_nload + n, D.b_nady + n, D.b_nvge + n};
+      for (int c = 0; c < 7; ++c) tnxe.push_back((uint16_t)nd[c]);
+    }
+  }
+  tmat.assign((size_t)N * N, (uint16_t)E);   // row-major = chunk order
+  for (int e = 0; e < E; ++e) {
+    tmat[(size_t)conn[2 * e] * N + conn[2 * e + 1]] = (uint16_t)e;
+    tmat[(size_t)conn[2 * e + 1] * N + conn[2 * e]] = (uint16_t)e;
+  }
+  D.nc_xn = (int32_t)txn.size() / 4;
+  D.nc_nxn = (int32_t)tnxn.size() / 4;
+  D.nc_nxe = (int32_t)tnxe.size() / 4;
+  D.nc_mat = (int32_t)tmat.size() / 4;
+  // pad to `iters` iterations of G chunks (entries past the end repeat the last chunk); chunk q = iteration q / G, lane q % G
+  auto padded = [&](const std::vector<uint16_t> &v, int iters) {
+    const size_t nc = v.size() / 4;
+    std::vector<uint16_t> out((size_t)iters * G * 4);
+    for (size_t q = 0; q < (size_t)iters * G; ++q)
+      for (int j = 0; j < 4; ++j) out[4 * q + j] = v[4 * std::min(q, nc - 1) + j];
+    return out;
+  };
+  // register tables: [pair][G][2]: the entries of iterations (2p, 2p+1) of a lane are adjacent
+  auto paired = [&](const std::vector<uint16_t> &v, int iters) {
+    const int ip = (iters + 1) / 2;
+    std::vector<uint16_t> lin = padded(v, 2 * ip), out(lin.size());
+    for (int p2 = 0; p2 < ip; ++p2)
+      for (int g = 0; g < G; ++g)
+        for (int h = 0; h < 2; ++h)
+          for (int j = 0; j < 4; ++j) out[(((size_t)p2 * G + g) * 2 + h) * 4 + j] = lin[((size_t)(2 * p2 + h) * G + g) * 4 + j];
+    return out;
+  };
+  std::vector<char> tab;
+  D.et_xn = (int32_t)tb_push(tab, paired(txn, IX));
+  D.et_nxn = (int32_t)tb_push(tab, paired(tnxn, IN_));
+  D.et_mat = (int32_t)tb_push(tab, paired(tmat, IM));
+  tab.resize((tab.size() + 15) & ~size_t(15));
+  t->etab = tb_dev_alloc(tab.size());
+  if (!t->etab || !tb_dev_upload(t->etab, tab.data(), tab.size())) {
+    if (t->etab) tb_dev_free(t->etab);
+    t->etab = nullptr;
+    return false;
+  }
+  D.etab = (const char *)t->etab;
+  D.f_tnxe = (int32_t)tb_push(blob, padded(tnxe, IE));   // LDS-resident, staged by EMIT launches only
+  blob.resize((blob.size() + 15) & ~size_t(15));
+  D.emit_ok = 1;
+  return true;
+}
 
 // --- DOF numbering, FEM_2Dtruss.py:227-261 ---------------------------------------------------
 static void tb_dof_numbering(const uint8_t *res, int N, std::vector<int32_t> &nsc, int &ndof) {
@@ -136,19 +290,6 @@ static std::vector<int> tb_rcm(int start, const std::vector<std::vector<int>> &a
     if (!seen[i]) bfs(i);
   std::reverse(order.begin(), order.end());
   return order;
-}
-
-static int tb_env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
-template <typename T>
-static size_t tb_push(std::vector<char> &blob, const std::vector<T> &v) {
-  size_t off = (blob.size() + 15) & ~size_t(15);
-  blob.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T));
-  if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
-  return off;
 }
 
 extern "C" int truss_abi_version(void) { return TRUSS_ABI_VERSION; }
@@ -416,6 +557,12 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
       }
   }
   size_t o_ar = tb_push(blob, area), o_isr = tb_push(blob, isr);
+  std::vector<float> areaf(n_sections), vsf(n_sections);
+  for (int i = 0; i < n_sections; ++i) {
+    areaf[i] = (float)area[i];
+    vsf[i] = (float)(area[i] / area[n_sections - 1]);   // truss2D_ENV.py:86-87 (area / truss[-1] area)
+  }
+  size_t o_arf = tb_push(blob, areaf), o_vsf = tb_push(blob, vsf);
   // load code of every z/P slot in team frames (see TopoDev::f_zcode)
   std::vector<uint8_t> zcode((size_t)zlen * nteams, 0);
   for (int tm = 0; tm < nteams; ++tm)
@@ -432,12 +579,6 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     }
   size_t o_ad = tb_push(blob, adj8), o_do = tb_push(blob, diagoff), o_zc = tb_push(blob, zcode);
   blob.resize((blob.size() + 15) & ~size_t(15));
-  t->blob = tb_dev_alloc(blob.size());
-  if (!t->blob || !tb_dev_upload(t->blob, blob.data(), blob.size())) {
-    if (t->blob) tb_dev_free(t->blob);
-    delete t;
-    return tb_fail(TRUSS_ENOMEM, "device allocation/upload of topology tables failed");
-  }
   TopoDev &D = t->dev;
   D.N = N;
   D.E = E;
@@ -449,7 +590,6 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.n_sym_elems = n_sym_elems;
   D.n_sections = n_sections;
   D.has_pairs = t->NP > 0 && 2 * t->NP == N;
-  D.blob = (const char *)t->blob;
   D.blob_bytes = (int32_t)blob.size();
   D.f_conn = (int32_t)o_conn;
   D.f_pairs = (int32_t)o_pairs;
@@ -462,6 +602,8 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.f_syme = (int32_t)o_se;
   D.f_area = (int32_t)o_ar;
   D.f_isr = (int32_t)o_isr;
+  D.f_areaf = (int32_t)o_arf;
+  D.f_vsf = (int32_t)o_vsf;
   D.f_adj8 = (int32_t)o_ad;
   D.f_diagoff = (int32_t)o_do;
   D.f_zcode = (int32_t)o_zc;
@@ -477,6 +619,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.long_stress = long_stress;
   // LDS layout: [copy of the blob][env 0][env 1]...; every array 16-byte aligned
   size_t off = 0;
+  std::vector<TbFrag> fr_early, fr_late;   // dead bytes for the bank of the fused observation writer (tb_build_emit)
   auto carve = [&](size_t bytes) {
     size_t o = off;
     off = (off + bytes + 15) & ~size_t(15);
@@ -502,6 +645,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     so += sizeof(double) * TRUSS_NRED * (size_t)t->G;
     D.o_kb = carve(std::max(band, so));
     D.o_red = D.o_kb + (int32_t)red_off;
+    fr_early.push_back({(size_t)D.o_kb + so, (size_t)D.o_kb + std::max(band, so)});
   }
   // solver scratch; before the solver the same bytes hold the per-element (k cc, k cs, k ss), after
   // the back substitution `red` (objective partials) reuses the z vectors
@@ -514,6 +658,8 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     D.o_ev = (int32_t)o0;
     size_t need = sizeof(double) * 3 * ((size_t)E + 1);
     if (off - o0 < need) off = (o0 + need + 15) & ~size_t(15);
+    fr_late.push_back({o0, (size_t)D.o_rbuf});                     // z vectors, solution vector
+    fr_late.push_back({(size_t)D.o_zring, off});                    // behind the reactions
   }
   D.o_par = carve(sizeof(double) * 8);
   D.o_y = carve(sizeof(float) * N);
@@ -526,6 +672,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
     D.o_mrg = (int32_t)o0;  // merge scratch of the two-sided solver: the actions are dead by then
     size_t need = nteams == 2 ? sizeof(double) * (size_t)(W * W + W) : 0;
     if (off - o0 < need) off = (o0 + need + 15) & ~size_t(15);
+    fr_early.push_back({o0, off});
   }
   D.o_sec = carve(sizeof(int32_t) * E);
   // stagger env regions across LDS banks: stride = 64 B (mod 256 B)
@@ -534,14 +681,33 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.env_stride = (int32_t)stride;
   D.o_env0 = (int32_t)((blob.size() + 255) & ~size_t(255));
   t->lds_bytes = D.o_env0 + stride * (64 / t->G);
+  tb_build_emit(t, conn, res, top, fr_early, fr_late, blob);   // may append the LDS-resident nN_x_e table to the blob
+  t->blob = tb_dev_alloc(blob.size());
+  if (!t->blob || !tb_dev_upload(t->blob, blob.data(), blob.size())) {
+    if (t->blob) tb_dev_free(t->blob);
+    if (t->etab) tb_dev_free(t->etab);
+    delete t;
+    return tb_fail(TRUSS_ENOMEM, "device allocation/upload of topology tables failed");
+  }
+  D.blob = (const char *)t->blob;
+  t->dev_emit = D;
+  t->dev_emit.blob_bytes = (int32_t)blob.size();
+  t->dev_emit.o_flag = (int32_t)blob.size();   // progress word right behind the staged tables
+  t->dev_emit.o_env0 = (int32_t)((blob.size() + 16 + 255) & ~size_t(255));
+  t->lds_bytes_emit = t->dev_emit.o_env0 + stride * (64 / t->G);
+  if (D.emit_ok && t->lds_bytes_emit > 160 * 1024) D.emit_ok = t->dev_emit.emit_ok = 0;
   if (tb_env_int("TRUSS_VERBOSE", 0))
     fprintf(stderr,
             "[truss_mi355] N=%d E=%d ndof=%d bw=%d | G=%d WL=%d RPL=%d EPL=%d teams=%d KA=%d mid=%d | tables %d B, "
-            "env %zu B, LDS/workgroup %zu B (%zu workgroups/CU)\n",
+            "env %zu B, LDS/workgroup %zu B (%zu workgroups/CU), fused observation writer %s\n",
             N, E, t->ndof, t->bw, t->G, t->WL, t->RPL, t->EPL, nteams, KA, mid, D.blob_bytes, stride, t->lds_bytes,
-            (size_t)(160 * 1024) / t->lds_bytes);
+            (size_t)(160 * 1024) / t->lds_bytes, D.emit_ok ? "yes" : "no");
+  if (tb_env_int("TRUSS_VERBOSE", 0) && D.emit_ok)
+    fprintf(stderr, "[truss_mi355]   fused launch: tables %d B, LDS/workgroup %zu B (%zu workgroups/CU)\n", t->dev_emit.blob_bytes,
+            t->lds_bytes_emit, (size_t)(160 * 1024) / t->lds_bytes_emit);
   if (t->lds_bytes > 160 * 1024) {
     tb_dev_free(t->blob);
+    if (t->etab) tb_dev_free(t->etab);
     delete t;
     return tb_fail(TRUSS_EUNSUPPORTED, "topology needs more than 160 KiB of LDS per workgroup");
   }
@@ -552,6 +718,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
 extern "C" int truss_topo_destroy(truss_topo_t *t) {
   if (!t) return TRUSS_OK;
   if (t->blob) tb_dev_free(t->blob);
+  if (t->etab) tb_dev_free(t->etab);
   delete t;
   return TRUSS_OK;
 }
@@ -572,6 +739,8 @@ extern "C" int truss_topo_solver_info(const truss_topo_t *t, int32_t *perm, int3
   if (rows_per_lane) *rows_per_lane = t->RPL;
   return TRUSS_OK;
 }
+
+extern "C" int truss_topo_fused_obs(const truss_topo_t *t) { return t && t->dev.emit_ok ? 1 : 0; }
 
 static int tb_make_step_args(const truss_topo_t *t, const truss_step_args_t *a, StepArgsDev &D) {
   if (!t || !a) return tb_fail(TRUSS_EINVAL, "NULL argument");
@@ -613,14 +782,55 @@ static int tb_make_step_args(const truss_topo_t *t, const truss_step_args_t *a, 
   D.energy = a->energy;
   D.react = a->reactions;
   D.status = a->status;
+  D.x_n = a->x_n;
+  D.A_s = a->A_s;
+  D.A_ts = a->A_n_ts;
+  D.A_cs = a->A_n_cs;
+  D.nxn = a->nN_x_n;
+  D.nxe = a->nN_x_e;
+  if (a->flags & TRUSS_F_EMIT_OBS) {
+    if (!a->sec_out || !a->max_up_out) return tb_fail(TRUSS_EINVAL, "TRUSS_F_EMIT_OBS needs sec_out and max_up_out / max_down_out");
+    if (!t->dev.emit_ok && tb_obs_lds_bytes(t->N) > 160 * 1024) return tb_fail(TRUSS_EUNSUPPORTED, "N too large for the observation kernel");
+  }
   return TRUSS_OK;
+}
+
+// One step; with TRUSS_F_EMIT_OBS the observation tensors come from the same launch where the topology allows
+// it (dev.emit_ok) and from the observation kernel, launched right behind the step on the same stream, elsewhere.
+static int tb_step_dispatch(const truss_topo *t, const StepArgsDev &D, void *stream) {
+  if (!(D.flags & TB_EMIT_OBS)) return tb_launch_step(t, D, false, stream);
+  if (t->dev.emit_ok) return tb_launch_step(t, D, true, stream);
+  int rc = tb_launch_step(t, D, false, stream);
+  if (rc != TRUSS_OK) return rc;
+  ObsArgsDev O;
+  O.B = D.B;
+  O.flags = 0;
+  O.x = D.x;
+  O.y = D.y_out;
+  O.sec = D.sec_out;
+  O.mu = D.mu_out;
+  O.md = D.md_out;
+  O.target = D.target;
+  O.disp = D.disp;
+  O.q0 = D.q0;
+  O.sr = D.sr;
+  O.comp = D.comp;
+  O.env_params = D.env_params;
+  O.x_n = D.x_n;
+  O.A_s = D.A_s;
+  O.A_ts = D.A_ts;
+  O.A_cs = D.A_cs;
+  O.nxn = D.nxn;
+  O.nxe = D.nxe;
+  O.tile_rows = tb_obs_tile_rows(t->N);
+  return tb_launch_obs(t, O, stream);
 }
 
 extern "C" int truss_step(const truss_topo_t *t, const truss_step_args_t *a, void *stream) {
   StepArgsDev D;
   int rc = tb_make_step_args(t, a, D);
   if (rc != TRUSS_OK) return rc;
-  return tb_launch_step(t, D, stream);
+  return tb_step_dispatch(t, D, stream);
 }
 
 extern "C" int truss_rollout(const truss_topo_t *t, const truss_step_args_t *a, int32_t n_steps, int32_t n_action_sets,
@@ -644,7 +854,7 @@ extern "C" int truss_rollout(const truss_topo_t *t, const truss_step_args_t *a, 
       S.a_geo = D.a_geo + (size_t)(s % n_action_sets) * gstride;
       S.a_topo = D.a_topo + (size_t)(s % n_action_sets) * tstride;
     }
-    rc = tb_launch_step(t, S, stream);
+    rc = tb_step_dispatch(t, S, stream);
     if (rc != TRUSS_OK) return rc;
   }
   return TRUSS_OK;

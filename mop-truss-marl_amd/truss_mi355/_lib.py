@@ -14,9 +14,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "csrc", "libtruss_mi355.so")
 
-TRUSS_ABI_VERSION = 2
+TRUSS_ABI_VERSION = 3
 F_NO_DECODE = 0x1
 F_CLAMP_INPLACE = 0x2
+F_EMIT_OBS = 0x4
 NPARAM = 8
 P_YMAX, P_DMIN, P_MAXDEF, P_LOADX, P_LOADY, P_INTOBJ1, P_INTOBJ2, P_ISROOF = range(8)
 
@@ -31,6 +32,7 @@ class StepArgs(C.Structure):
         ("y_out", _vp), ("sec_out", _vp), ("max_up_out", _vp), ("max_down_out", _vp),
         ("disp", _vp), ("q0", _vp), ("sr", _vp), ("comp", _vp), ("point", _vp), ("obj", _vp),
         ("disp_f64", _vp), ("q0_f64", _vp), ("energy", _vp), ("reactions", _vp), ("status", _vp),
+        ("x_n", _vp), ("A_s", _vp), ("A_n_ts", _vp), ("A_n_cs", _vp), ("nN_x_n", _vp), ("nN_x_e", _vp),
     ]
 
 
@@ -82,6 +84,8 @@ class TrussLib:
         d.truss_topo_dofs.argtypes = [_vp, _vp, _vp]
         d.truss_topo_solver_info.restype = C.c_int
         d.truss_topo_solver_info.argtypes = [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        d.truss_topo_fused_obs.restype = C.c_int
+        d.truss_topo_fused_obs.argtypes = [_vp]
         d.truss_step.restype = C.c_int
         d.truss_step.argtypes = [_vp, C.POINTER(StepArgs), _vp]
         d.truss_rollout.restype = C.c_int

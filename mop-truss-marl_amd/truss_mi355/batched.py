@@ -19,6 +19,11 @@ from . import _lib
 from .topology import TrussTopology
 
 
+import contextlib
+
+_NULL_CTX = contextlib.nullcontext()
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -42,7 +47,9 @@ class BatchedTruss:
         if self.lib.backend == "hip" and self.device.type != "cuda":
             raise _lib.TrussError("the HIP library needs tensors on a cuda (ROCm) device")
         self.topo = topo
-        self.h = topo.native(self.lib)
+        # the native topology owns device tables: one handle per (library, device), created on THIS device
+        with self._on_device():
+            self.h = topo.native(self.lib, self.device.index if self.device.type == "cuda" else None)
         self.B, self.N, self.E = int(n_envs), topo.N, topo.E
         _, _, self.ndof = topo.dofs(self.lib)
         B, N, E = self.B, self.N, self.E
@@ -89,7 +96,47 @@ class BatchedTruss:
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
 
-    def _args(self, flags, a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy=True, n_envs=None):
+    def _on_device(self):
+        """Native launches go to the CURRENT HIP device: make it this env's device for the call (a no-op
+        context on the one-rank-per-GPU path, where it already is)."""
+        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
+            return torch.cuda.device(self.device)
+        return _NULL_CTX
+
+    OBS_KEYS = ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e")
+
+    def obs_buffers(self):
+        """The env's own observation tensors (allocated on first use)."""
+        if not hasattr(self, "_obs"):
+            B, N, E = self.B, self.N, self.E
+            mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
+            self._obs = dict(x_n=mk(B, N, 13), A_s=mk(B, N, N), A_n_ts=mk(B, N, N), A_n_cs=mk(B, N, N),
+                             nN_x_n=mk(B, N, 12), nN_x_e=mk(B, E, 21))
+        return self._obs
+
+    def _obs_out(self, out, nact):
+        """Validated observation outputs: None -> the env's own buffers; a dict may leave tensors out."""
+        if out is None or out is True:
+            return self.obs_buffers()
+        N, E = self.N, self.E
+        shapes = dict(x_n=(N, 13), A_s=(N, N), A_n_ts=(N, N), A_n_cs=(N, N), nN_x_n=(N, 12), nN_x_e=(E, 21))
+        for k in self.OBS_KEYS:
+            t = out.get(k)
+            if t is None:
+                continue
+            if (t.dim() != 3 or t.shape[0] < nact or tuple(t.shape[1:]) != shapes[k] or t.dtype != torch.float32
+                    or not t.is_contiguous() or t.device != self.device):
+                raise ValueError(f"obs[{k}]: expected contiguous float32 [>={nact}, {shapes[k][0]}, {shapes[k][1]}] on "
+                                 f"{self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+        return out
+
+    @property
+    def fused_obs(self):
+        """True when step(obs=...) writes the observations from the step's own launch for this topology."""
+        return bool(self.lib.dll.truss_topo_fused_obs(self.h))
+
+    def _args(self, flags, a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy=True, n_envs=None,
+              obs=None):
         a = _lib.StepArgs()
         a.struct_size = C.sizeof(_lib.StepArgs)
         a.n_envs, a.flags = (self.B if n_envs is None else int(n_envs)), flags
@@ -105,6 +152,10 @@ class BatchedTruss:
         a.energy = _ptr(self.energy) if want_energy else None
         a.reactions = _ptr(self.reactions) if want_energy else None
         a.status = _ptr(self.status)
+        if obs is not None:
+            a.flags |= _lib.F_EMIT_OBS
+            a.x_n, a.A_s, a.A_n_ts, a.A_n_cs = (_ptr(obs.get(k)) for k in ("x_n", "A_s", "A_n_ts", "A_n_cs"))
+            a.nN_x_n, a.nN_x_e = _ptr(obs.get("nN_x_n")), _ptr(obs.get("nN_x_e"))
         return a
 
     def _chk(self, t, shape, dtype, name):
@@ -142,25 +193,39 @@ class BatchedTruss:
             raise ValueError(f"n_active {n} outside 0..{self.B}")
         return n
 
-    def analyze(self, set_normalisers: bool = False, n_active=None):
+    def analyze(self, set_normalisers: bool = False, n_active=None, obs=None):
         """Model.restore(); Model.gen_all() on the current design (reset path).  With
         set_normalisers the raw objectives become int_obj1/int_obj2 (Game_research04.__init__,
         truss2D_ENV.py:264-274).  n_active: only the first n envs of the resident buffers (callers that
-        compact their live envs to the front, truss_mi355/marl.py)."""
+        compact their live envs to the front, truss_mi355/marl.py).  obs: True / dict -> also write the
+        observation tensors (`_game_get_1_state`, truss2D_ENV.py:336-351) in the same native call."""
+        n = self._n(n_active)
+        if n == 0:
+            return None
+        out = None if obs is None or obs is False else self._obs_out(obs, n)
         a = self._args(_lib.F_NO_DECODE, None, None, None, None, None, self.y, self.sec, self.y, self.sec,
-                       n_envs=self._n(n_active))
-        self.lib.check(self.lib.dll.truss_step(self.h, C.byref(a), self._stream()), "truss_step(analyze)")
+                       n_envs=n, obs=out)
+        with self._on_device():
+            self.lib.check(self.lib.dll.truss_step(self.h, C.byref(a), self._stream()), "truss_step(analyze)")
         if set_normalisers:
             self.env_params[:, _lib.P_INTOBJ1] = self.obj[:, 0].double()
             self.env_params[:, _lib.P_INTOBJ2] = self.obj[:, 1].double()
             self.point[:, 0] = 1.0
             self.point[:, 1] = 1.0
+        return out
 
     # ---- the transition ---------------------------------------------------------------------
-    def step(self, a_geo, a_topo, coin=None, max_up_in=None, max_down_in=None, clamp_inplace=False, n_active=None):
+    def step(self, a_geo, a_topo, coin=None, max_up_in=None, max_down_in=None, clamp_inplace=False, n_active=None,
+             obs=None):
         """One `_game_modify` per env from the current design; the new design becomes current.
-        a_geo [B,N,2], a_topo [B,N,3] float32 on the env's device ([n_active, ...] with n_active)."""
+        a_geo [B,N,2], a_topo [B,N,3] float32 on the env's device ([n_active, ...] with n_active).
+        obs: True (the env's own buffers) or a dict of output tensors -> the observation tensors of the new
+        design (state_data + state_data_not_norm, truss2D_ENV.py:497-500) are written by the same native call
+        -- by the same kernel launch where `fused_obs` -- and returned."""
         B, N = self._n(n_active), self.N
+        if B == 0:
+            return None
+        out = None if obs is None or obs is False else self._obs_out(obs, B)
         if coin is None:
             coin = self._coin0
         nxt = self.cur ^ 1
@@ -168,7 +233,8 @@ class BatchedTruss:
         # an RL loop passes the same buffers every step: validated argument blocks are kept per buffer set
         key = (self.cur, flags, a_geo.data_ptr(), a_topo.data_ptr(), coin.data_ptr(),
                0 if max_up_in is None else max_up_in.data_ptr(), 0 if max_down_in is None else max_down_in.data_ptr(),
-               a_geo.shape, a_topo.shape, a_geo.dtype, a_topo.dtype, a_geo.is_contiguous(), a_topo.is_contiguous(), B)
+               a_geo.shape, a_topo.shape, a_geo.dtype, a_topo.dtype, a_geo.is_contiguous(), a_topo.is_contiguous(), B,
+               None if out is None else tuple(0 if out.get(k) is None else out[k].data_ptr() for k in self.OBS_KEYS))
         a = self._step_cache.get(key)
         if a is None:
             self._chk(a_geo, (B, N, 2), torch.float32, "a_geo")
@@ -178,14 +244,16 @@ class BatchedTruss:
             self._chk(max_up_in, (B, N), torch.float32, "max_up_in")
             self._chk(max_down_in, (B, N), torch.float32, "max_down_in")
             a = self._args(flags, a_geo, a_topo, coin, max_up_in, max_down_in, self.ybuf[self.cur], self.secbuf[self.cur],
-                           self.ybuf[nxt], self.secbuf[nxt], n_envs=B)
+                           self.ybuf[nxt], self.secbuf[nxt], n_envs=B, obs=out)
             if len(self._step_cache) > 64:
                 self._step_cache.clear()
             self._step_cache[key] = a
-        rc = self.lib.dll.truss_step(self.h, C.byref(a), self._stream())
+        with self._on_device():
+            rc = self.lib.dll.truss_step(self.h, C.byref(a), self._stream())
         if rc:
             self.lib.check(rc, "truss_step")
         self.cur = nxt
+        return out
 
     def rollout(self, a_geo_sets, a_topo_sets, n_steps, coin=None):
         """n_steps chained transitions in one native call; action set s % S is used at step s.
@@ -198,8 +266,9 @@ class BatchedTruss:
         nxt = self.cur ^ 1
         a = self._args(0, a_geo_sets, a_topo_sets, coin, None, None, self.ybuf[self.cur], self.secbuf[self.cur],
                        self.ybuf[nxt], self.secbuf[nxt], want_energy=False)
-        self.lib.check(self.lib.dll.truss_rollout(self.h, C.byref(a), int(n_steps), int(S), self._stream()),
-                       "truss_rollout")
+        with self._on_device():
+            self.lib.check(self.lib.dll.truss_rollout(self.h, C.byref(a), int(n_steps), int(S), self._stream()),
+                           "truss_rollout")
         if n_steps & 1:
             self.cur = nxt
 
@@ -208,20 +277,18 @@ class BatchedTruss:
         analysis, for every env: x_n[B,N,13], A_s/A_n_ts/A_n_cs[B,N,N], nN_x_n[B,N,12], nN_x_e[B,E,21]
         (device tensors).  A_n, mask and nC_e are topology-static: TrussTopology.normalized_adjacency()
         / .incidence()."""
-        B, N, E = self.B, self.N, self.E
-        if out is None:
-            if not hasattr(self, "_obs"):
-                f32 = torch.float32
-                mk = lambda *sh: torch.empty(sh, dtype=f32, device=self.device)
-                self._obs = dict(x_n=mk(B, N, 13), A_s=mk(B, N, N), A_n_ts=mk(B, N, N), A_n_cs=mk(B, N, N),
-                                 nN_x_n=mk(B, N, 12), nN_x_e=mk(B, E, 21))
-            out = self._obs
         nact = self._n(n_active)
+        key0 = None if out is None else tuple(0 if out.get(k) is None else out[k].data_ptr() for k in self.OBS_KEYS)
+        if out is None or (self.cur, id(out), nact) + key0 not in self._obs_cache:
+            out = self._obs_out(out, nact)
+        if nact == 0:
+            return out
         key = (self.cur, id(out), nact) + tuple(0 if out.get(k) is None else out[k].data_ptr()
                                                 for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e"))
         a = self._obs_cache.get(key)
         if a is not None:
-            rc = self.lib.dll.truss_obs(self.h, C.byref(a), self._stream())
+            with self._on_device():
+                rc = self.lib.dll.truss_obs(self.h, C.byref(a), self._stream())
             if rc:
                 self.lib.check(rc, "truss_obs")
             return out
@@ -237,7 +304,8 @@ class BatchedTruss:
         if len(self._obs_cache) > 16:
             self._obs_cache.clear()
         self._obs_cache[key] = a
-        self.lib.check(self.lib.dll.truss_obs(self.h, C.byref(a), self._stream()), "truss_obs")
+        with self._on_device():
+            self.lib.check(self.lib.dll.truss_obs(self.h, C.byref(a), self._stream()), "truss_obs")
         return out
 
     def results(self):

@@ -89,8 +89,14 @@ class TrussTopology:
         return cls(conn, res, top, pair, sym_nodes, sym_elems, node_order=order, num_x=nx)
 
     # ---- native handle ----
-    def native(self, lib: "_lib.TrussLib"):
-        key = lib.path
+    def native(self, lib: "_lib.TrussLib", device_index=None):
+        """Native handle (host tables + device blob).  The blob is allocated on the HIP device that is current
+        at creation: handles are cached per (library, device index); `device_index` None = the current device
+        (BatchedTruss passes its own and makes that device current around the call)."""
+        if device_index is None and lib.backend == "hip":
+            import torch
+            device_index = torch.cuda.current_device()
+        key = (lib.path, device_index)
         if key not in self._native:
             h = C.c_void_p()
 

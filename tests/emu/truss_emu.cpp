@@ -24,6 +24,20 @@ static inline double tb_rcp(double d) { return 1.0 / d; }
 template <class LN>
 static inline double tb_team_bcast(LN &ln, int src) { return ln.peers[ln.lane - ln.gs + src].bx; }
 static inline double tb_rsqrt(double x) { return 1.0 / sqrt(x); }
+static inline float tb_rcpf(float d) { return 1.0f / d; }
+// min / max over the lanes of an env: the partials the lanes left in the previous phase
+template <class LN>
+static inline float tb_group_min(LN &ln, int c) {
+  float v = INFINITY;
+  for (int j = 0; j < LN::G_; ++j) v = fminf(v, ln.peers[ln.lane - ln.g + j].pmn[c]);
+  return v;
+}
+template <class LN>
+static inline float tb_group_max(LN &ln, int c) {
+  float v = -INFINITY;
+  for (int j = 0; j < LN::G_; ++j) v = fmaxf(v, ln.peers[ln.lane - ln.g + j].pmx[c]);
+  return v;
+}
 
 #include "../../mop-truss-marl_amd/csrc/truss_body.h"
 
@@ -35,41 +49,52 @@ static bool tb_dev_upload(void *dst, const void *src, size_t n) {
   memcpy(dst, src, n);
   return true;
 }
-static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *stream);
+static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *stream);
 static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream);
 
 #include "../../mop-truss-marl_amd/csrc/truss_host.h"
 
-template <int G, int WL, int RPL, int EPL>
+template <int G, int WL, int RPL, int EPL, bool EMIT>
 static void emu_run(const truss_topo *t, const StepArgsDev &A) {
-  using Lane = StepLane<G, WL, RPL, EPL>;
+  using Lane = StepLane<G, WL, RPL, EPL, EMIT>;
   constexpr int W_ = Lane::W;
-  const TopoDev &T = t->dev;
+  constexpr bool EMIT_ = EMIT;
+  const TopoDev &T = EMIT ? t->dev_emit : t->dev;
   const int nblocks = (A.B + Lane::EPB - 1) / Lane::EPB;
-  std::vector<char> lds(t->lds_bytes);
+  std::vector<char> lds(EMIT ? t->lds_bytes_emit : t->lds_bytes);
   std::vector<Lane> lanes(64);
   for (int b = 0; b < nblocks; ++b) {
     memset(lds.data(), 0xA5, lds.size());  // poison: catches reads of uninitialised LDS
     for (int l = 0; l < 64; ++l) {
       lanes[l].init(l, b, T, A, lds.data());
       lanes[l].peers = lanes.data();
+      lanes[l].emit_tables_load(T);   // (HIP: the streaming wave of an EMIT workgroup)
     }
 #define PH(call) \
   for (auto &ln : lanes) ln.call
 #define PH_NS(call) \
   for (auto &ln : lanes) ln.call
 #define BAR() (void)0
+#define EMIT_POINT(k) TRUSS_STREAM_SEG##k(PH, T, A)   /* HIP: the streaming wave's work; here: in place */
     TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
 #undef PH
 #undef PH_NS
 #undef BAR
+#undef EMIT_POINT
   }
 }
 
-static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, void *) {
+static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *) {
   const TbVariant &v = kVariants[t->variant];
+  if (emit) {
 #define X(g, wl, r, e) \
-  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) { emu_run<g, wl, r, e>(t, A); return TRUSS_OK; }
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) { emu_run<g, wl, r, e, true>(t, A); return TRUSS_OK; }
+    TRUSS_EMIT_VARIANTS(X)
+#undef X
+    return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled with the observation writer");
+  }
+#define X(g, wl, r, e) \
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) { emu_run<g, wl, r, e, false>(t, A); return TRUSS_OK; }
   TRUSS_VARIANTS(X)
 #undef X
   return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled into the emulator");

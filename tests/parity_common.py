@@ -97,8 +97,9 @@ def compare_step(r, o, otopo, tight=1e-9, pt_tol=0.0, zero_force=0.0):
     assert rel(r["reactions"][:, :nr], o["fem"]["r"][:, otopo.ndof:]) < max(tight, 1e-8)
 
 
-def run_golden_transitions(lib, name):
-    """Replay the reference's recorded `_game_modify` transitions through the native step."""
+def run_golden_transitions(lib, name, obs=None):
+    """Replay the reference's recorded `_game_modify` transitions through the native step.
+    obs=True: the step also writes the observation tensors (TRUSS_F_EMIT_OBS) into the env's buffers."""
     nx, var = SCENARIOS[name]
     f = np.load(os.path.join(GOLDEN, name + ".npz"))
     topo = tm.TrussTopology.grid(nx, var)
@@ -118,7 +119,7 @@ def run_golden_transitions(lib, name):
     coin = torch.tensor((f["tr_coin"] >= 0.5).astype(np.uint8), device=dev)
     mu = torch.tensor(f["tr_stale_max_up"].astype(np.float32), device=dev)
     md = torch.tensor(f["tr_stale_max_down"].astype(np.float32), device=dev)
-    env.step(geo, tac, coin, mu, md, clamp_inplace=True)
+    env.step(geo, tac, coin, mu, md, clamp_inplace=True, obs=obs)
     r = env.results()
     # --- against the reference's own outputs ---
     assert np.array_equal(geo.cpu().numpy(), f["tr_clamped_geo"])
@@ -202,9 +203,10 @@ def run_random_rollout(lib, num_x, n_extra, B, n_steps, seed, symmetry=None, top
     return env
 
 
-def compare_obs(env, o):
-    """native observation tensors vs the oracle's (float32; 1e-6 relative to the column scale)."""
-    obs = {k: v.cpu().numpy() for k, v in env.observe().items()}
+def compare_obs(env, o, obs=None):
+    """native observation tensors vs the oracle's (float32; 1e-6 relative to the column scale).
+    obs: tensors a step(obs=...) call has written; None = run the observation kernel."""
+    obs = {k: v.cpu().numpy() for k, v in (env.observe() if obs is None else obs).items()}
     for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e"):
         a, b = obs[k], o[k]
         assert a.shape == b.shape, k
@@ -214,7 +216,9 @@ def compare_obs(env, o):
     return obs
 
 
-def run_obs_random(lib, num_x, n_extra, B, seed):
+def run_obs_random(lib, num_x, n_extra, B, seed, fused=False, expect_one_launch=None):
+    """fused: the observation tensors come out of the step call itself (TRUSS_F_EMIT_OBS) and are compared with the
+    oracle AND with what the stand-alone observation kernel writes for the same step."""
     topo = synthetic.bench_topology(num_x, n_extra) if n_extra else tm.TrussTopology.grid(num_x)
     batch = synthetic.random_batch(topo, B, seed)
     env = make_env(lib, topo, batch)
@@ -223,17 +227,30 @@ def run_obs_random(lib, num_x, n_extra, B, seed):
     load = oracle_load(ot, batch)
     int_obj = O.initial_objectives(ot, batch["x"], batch["y"], batch["sec"], batch["target"])
     ag, at = synthetic.random_actions(1, B, topo.N, seed + 1)
-    env.step(torch.tensor(ag[0], device=env.device), torch.tensor(at[0], device=env.device))
+    got = None
+    if fused:
+        if expect_one_launch is not None:
+            assert env.fused_obs == expect_one_launch
+        got = {k: torch.full_like(v, float("nan")) for k, v in env.obs_buffers().items()}   # every element must be written
+    env.step(torch.tensor(ag[0], device=env.device), torch.tensor(at[0], device=env.device), obs=got)
     o = O.env_step(ot, batch["x"], batch["y"], batch["sec"], None, None, ag[0], at[0], np.zeros(B), batch["target"],
                    load, batch["y_max"], batch["d_min"], batch["max_def"], batch["is_roof"], int_obj, with_obs=True)
-    compare_obs(env, o)
+    if fused:
+        a = compare_obs(env, o, got)
+        b = compare_obs(env, o)
+        for k in a:     # same staged rows; element length by rsqrt-Newton vs sqrt, normalisation by reciprocal vs division
+            np.testing.assert_allclose(a[k], b[k], rtol=4e-7, atol=1e-7, err_msg=k)
+    else:
+        compare_obs(env, o)
+    return env
 
 
-def run_obs_golden(lib, name):
-    """observation tensors of the replayed golden transitions vs the reference's own arrays."""
-    env = run_golden_transitions(lib, name)
+def run_obs_golden(lib, name, fused=False):
+    """observation tensors of the replayed golden transitions vs the reference's own arrays; fused: as written by
+    the step call itself (TRUSS_F_EMIT_OBS) instead of the stand-alone observation kernel."""
+    env = run_golden_transitions(lib, name, obs=True if fused else None)
     f = np.load(os.path.join(GOLDEN, name + ".npz"))
-    obs = {k: v.cpu().numpy() for k, v in env.observe().items()}
+    obs = {k: v.cpu().numpy() for k, v in (env.obs_buffers() if fused else env.observe()).items()}
     for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n"):
         np.testing.assert_allclose(obs[k], f["tr_out_" + k], rtol=1e-5, atol=5e-6, err_msg=k)
     xe, ref = obs["nN_x_e"], f["tr_out_nN_x_e"]

@@ -40,6 +40,19 @@ def test_observation_tensors_random_emulated(lib):
     pc.run_obs_random(lib, 6, 0, 3, seed=22)
 
 
+@pytest.mark.parametrize("name", ["train0", "train_eval", "small_roof", "large_bridge", "large_roof"])
+def test_fused_observation_golden_emulated(lib, name):
+    """TRUSS_F_EMIT_OBS: the step writes the observation tensors itself; against the reference's recorded arrays."""
+    pc.run_obs_golden(lib, name, fused=True)
+
+
+def test_fused_observation_random_emulated(lib):
+    pc.run_obs_random(lib, 16, 4, 7, seed=21, fused=True, expect_one_launch=True)    # 32 / 80: the metric topology
+    pc.run_obs_random(lib, 16, 0, 5, seed=23, fused=True, expect_one_launch=True)    # 32 / 76
+    pc.run_obs_random(lib, 8, 0, 6, seed=24, fused=True, expect_one_launch=True)     # 16 / 36
+    pc.run_obs_random(lib, 6, 0, 3, seed=22, fused=True, expect_one_launch=False)    # 12 / 26: E % 4 != 0 -> two launches
+
+
 def test_symmetric_variants_random(lib):
     pc.run_random_rollout(lib, 8, 0, 9, 2, seed=5, symmetry="small")
     pc.run_random_rollout(lib, 16, 0, 6, 2, seed=6, symmetry="large")
@@ -135,7 +148,7 @@ def test_hip_library_exports_every_declared_symbol():
     dll.truss_backend.restype = ctypes.c_char_p
     assert dll.truss_backend() == b"hip"
     dll.truss_abi_version.restype = ctypes.c_int
-    assert dll.truss_abi_version() == 2
+    assert dll.truss_abi_version() == tm._lib.TRUSS_ABI_VERSION == 3
 
 
 def test_product_refuses_non_hip_default(monkeypatch, tmp_path):

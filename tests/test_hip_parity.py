@@ -46,6 +46,60 @@ def test_observation_tensors_random(lib):
     pc.run_obs_random(lib, 6, 0, 17, seed=22)
 
 
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_fused_observation_golden(lib, name):
+    """TRUSS_F_EMIT_OBS: the observation tensors written by the step's own launch vs the reference's arrays."""
+    pc.run_obs_golden(lib, name, fused=True)
+
+
+def test_fused_observation_random(lib):
+    pc.run_obs_random(lib, 16, 4, 129, seed=21, fused=True, expect_one_launch=True)   # 32 / 80, ragged last workgroup
+    pc.run_obs_random(lib, 16, 0, 64, seed=23, fused=True, expect_one_launch=True)    # 32 / 76
+    pc.run_obs_random(lib, 8, 0, 65, seed=24, fused=True, expect_one_launch=True)     # 16 / 36
+    pc.run_obs_random(lib, 6, 0, 17, seed=22, fused=True, expect_one_launch=False)    # 12 / 26 -> step + observation kernel
+    pc.run_obs_random(lib, 64, 0, 6, seed=64, fused=True, expect_one_launch=False)    # 128 nodes -> two launches
+
+
+def test_fused_observation_full_size(lib):
+    """4096 envs, 32 nodes / 80 elements: the fused launch writes what step + observation kernel write, and leaves the
+    step's own results untouched; a 128-env sample agrees with the oracle; the reset path (NO_DECODE) emits too."""
+    topo = synthetic.bench_topology(16, 4)
+    B = 4096
+    batch = synthetic.random_batch(topo, B, 77)
+    ag, at = synthetic.random_actions(1, B, topo.N, 78)
+    e1, e2 = pc.make_env(lib, topo, batch), pc.make_env(lib, topo, batch)
+    assert e1.fused_obs
+    for e in (e1, e2):
+        e.analyze(set_normalisers=True)
+    g0, t0 = torch.tensor(ag[0], device=e1.device), torch.tensor(at[0], device=e1.device)
+    got = {k: torch.full_like(v, float("nan")) for k, v in e1.obs_buffers().items()}
+    e1.step(g0, t0, obs=got)
+    e2.step(g0, t0)
+    ref = e2.observe()
+    r1, r2 = e1.results(), e2.results()
+    for k in ("y", "sec", "point", "disp", "q0", "sr", "comp", "max_up", "max_down", "status"):
+        assert np.array_equal(r1[k], r2[k]), k
+    for k, v in got.items():
+        a, b = v.cpu().numpy(), ref[k].cpu().numpy()
+        assert np.isfinite(a).all(), k
+        np.testing.assert_allclose(a, b, rtol=4e-7, atol=1e-7, err_msg=k)
+    idx = np.random.default_rng(1).choice(B, 128, replace=False)
+    ot = pc.oracle_topology(topo)
+    sub = {k: v[idx] for k, v in batch.items()}
+    int_obj = O.initial_objectives(ot, sub["x"], sub["y"], sub["sec"], sub["target"])
+    o = O.env_step(ot, sub["x"], sub["y"], sub["sec"], None, None, ag[0][idx], at[0][idx], np.zeros(128), sub["target"],
+                   pc.oracle_load(ot, sub), sub["y_max"], sub["d_min"], sub["max_def"], sub["is_roof"], int_obj, with_obs=True)
+    for k, v in got.items():
+        a, b = v.cpu().numpy()[idx], o[k]
+        scale = np.maximum(np.abs(b).reshape(-1, b.shape[-1]).max(axis=0), 1.0)
+        assert float((np.abs(a - b) / scale).max()) < 2e-6, k
+    # reset path: analysis + observation of the current design in one call
+    got2 = e1.analyze(obs=True)
+    ref2 = e1.observe({k: torch.empty_like(v) for k, v in got2.items()})
+    for k in got2:
+        np.testing.assert_allclose(got2[k].cpu().numpy(), ref2[k].cpu().numpy(), rtol=4e-7, atol=1e-7, err_msg=k)
+
+
 def test_full_size_properties(lib):
     """BASELINE size (32 nodes / 80 elements / 4096 envs): size-independent properties.
     (1) a random 256-env sample agrees with the oracle; (2) equilibrium: reactions balance the applied
