@@ -129,11 +129,12 @@ struct TopoDev {
   int32_t nc_xn, nc_nxn, nc_nxe, nc_mat;   // chunks per env
   // feature bank: float offsets (from the env's LDS base) of the arrays the tables point into; they live in
   // bytes of the env that are dead by the time they are written (band, solver scratch, action rows)
-  int32_t b_const;                                            // [0] = 0, [1] = 1, [2] = 1 / (1 + 1e-6f)
-  int32_t b_nload, b_nt9, b_nady, b_nvge;                     // per node: raw features the step does not hold as rows
-  int32_t b_xn[9];                                            // per node: normalised columns 0 1 4 7 8 9 10 11 12 of x_n
-  int32_t b_esec, b_earea, b_elen, b_etens, b_ecomp, b_eviol; // per element: nN_x_e columns 0 1 2 3 4 6 (post_elements)
-  int32_t b_ev2;                                              // per element (+1 zero record): float2 (A_n_ts, A_n_cs) values
+  int32_t b_const;   // [0] = 0, [1] = 1, [2] = 1 / (1 + 1e-6f)
+  // records (LDS stores are the expensive instruction here: two / four 16-byte stores per element / node)
+  int32_t b_erec;    // per element, 8 floats: sec, area, length, tension, compression, violated (nN_x_e columns 0 1 2 3 4 6),
+                     //   A_n_ts value, A_n_cs value (ENV:92-100); + one all-zero record E ("no edge")
+  int32_t b_nraw;    // per node, 4 floats: loaded, target / y, |dy|, |dy| / max_def >= 1 (features the step holds in no row)
+  int32_t b_nna, b_nnb, b_nn8;   // per node: normalised x_n columns (0 1 4 7), (8 9 10 11) as 4-float records, column 12 as floats
 };
 
 #define TB_TAB(type, base, off) ((const type *)((base) + (off)))
@@ -1157,7 +1158,7 @@ struct StepLane {
   static constexpr int IM = EMIT ? (NF * NF / 4 + G - 1) / G : 1;     //                  each N x N matrix
   static constexpr int NDYN = 9;                                      // x_n columns 0 1 4 7 8 9 10 11 12 vary per env
   static constexpr int KB = 8;                                        // chunks gathered back to back before their stores
-  tb_u2 etx[IX], etn[IN_], etm[IM];
+  tb_u2 etx[IX], etn[IN_], etm[IM], ete[IE];
   float el[EMIT ? EPL : 1];           // element lengths (phase_elements)
   float nfe[EMIT ? NPL : 1][NDYN];    // raw dynamic columns of the lane's nodes
   float pmn[NDYN], pmx[NDYN];         // partial column min / max over the lane's nodes
@@ -1224,7 +1225,7 @@ struct StepLane {
   TRUSS_HD void obs_emit_tc(const TopoDev &T, const StepArgsDev &A) {
     if constexpr (EMIT) {
       if (!active || (!A.A_ts && !A.A_cs)) return;
-      const tb_f2 *R = (const tb_f2 *)((const float *)L + T.b_ev2);
+      const tb_f2 *R = (const tb_f2 *)((const float *)L + T.b_erec) + 3;   // (A_n_ts, A_n_cs) = floats 6, 7 of an 8-float record
       const size_t nn4 = (size_t)T.N * T.N / 4;
       tb_f4 *pt = (tb_f4 *)A.A_ts + env * nn4, *pc = (tb_f4 *)A.A_cs + env * nn4;
 #pragma unroll
@@ -1235,10 +1236,10 @@ struct StepLane {
           for (int k = 0; k < KB; ++k)
             if (b0 + k < IM) {
               const tb_u2 t = etm[b0 + k];
-              r[k][0] = R[t[0] & 0xffffu];
-              r[k][1] = R[t[0] >> 16];
-              r[k][2] = R[t[1] & 0xffffu];
-              r[k][3] = R[t[1] >> 16];
+              r[k][0] = R[4 * (t[0] & 0xffffu)];
+              r[k][1] = R[4 * (t[0] >> 16)];
+              r[k][2] = R[4 * (t[1] & 0xffffu)];
+              r[k][3] = R[4 * (t[1] >> 16)];
             }
 #pragma unroll
           for (int k = 0; k < KB; ++k)
@@ -1271,18 +1272,15 @@ struct StepLane {
         const float srv = SR[ee];
         const bool cmp = CP[ee] != 0;
         const float val = fminf(srv, 1.0f) * (srv > 1.0f ? 1.0f : 0.5f);
-        Lf[T.b_esec + ee] = (float)sc;
-        Lf[T.b_earea + ee] = AF[sc];
-        Lf[T.b_elen + ee] = el[i];
-        Lf[T.b_etens + ee] = cmp ? 0.0f : 1.0f;
-        Lf[T.b_ecomp + ee] = cmp ? 1.0f : 0.0f;
-        Lf[T.b_eviol + ee] = srv > 1.0f ? 1.0f : 0.0f;
-        const tb_f2 rec = {cmp ? 0.0f : val, cmp ? val : 0.0f};
-        ((tb_f2 *)(Lf + T.b_ev2))[ee] = rec;
+        const tb_f4 r0 = {(float)sc, AF[sc], el[i], cmp ? 0.0f : 1.0f};
+        const tb_f4 r1 = {cmp ? 1.0f : 0.0f, srv > 1.0f ? 1.0f : 0.0f, cmp ? 0.0f : val, cmp ? val : 0.0f};
+        tb_f4 *rec = (tb_f4 *)(Lf + T.b_erec) + 2 * ee;
+        rec[0] = r0;
+        rec[1] = r1;
       }
       if (g == 0) {
-        const tb_f2 z = {0.0f, 0.0f};
-        ((tb_f2 *)(Lf + T.b_ev2))[T.E] = z;                             // the "no edge" record
+        const tb_f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        ((tb_f4 *)(Lf + T.b_erec))[2 * T.E + 1] = z;                    // the "no edge" record (its A_n_ts / A_n_cs half)
         Lf[T.b_const + 0] = 0.0f;
         Lf[T.b_const + 1] = 1.0f;
         Lf[T.b_const + 2] = (1.0f - 0.0f) / (1.0f - 0.0f + 1e-6f);   // a 0/1 column with both values present
@@ -1321,10 +1319,8 @@ struct StepLane {
         const float ratio = f[6] / maxdef32;
         f[7] = fminf(ratio, 1.0f) * (ratio > 1.0f ? 1.0f : 0.5f);
         f[8] = ratio > 1.0f ? 1.0f : 0.0f;
-        Lf[T.b_nload + nc] = f[2];
-        Lf[T.b_nt9 + nc] = f[5];
-        Lf[T.b_nady + nc] = f[6];
-        Lf[T.b_nvge + nc] = ratio >= 1.0f ? 1.0f : 0.0f;
+        const tb_f4 raw = {f[2], f[5], f[6], ratio >= 1.0f ? 1.0f : 0.0f};
+        ((tb_f4 *)(Lf + T.b_nraw))[nc] = raw;
         if (n < T.N) {
 #pragma unroll
           for (int c = 0; c < NDYN; ++c) {
@@ -1340,6 +1336,7 @@ struct StepLane {
   TRUSS_HD void obs_bank_fill(const TopoDev &T, const StepArgsDev &A) {
     if constexpr (EMIT) {
       float *Lf = (float *)L;
+      float nv[NPL][NDYN];
 #pragma unroll
       for (int c = 0; c < NDYN; ++c) {
         const float lo = tb_group_min(*this, c), hi = tb_group_max(*this, c);
@@ -1347,10 +1344,16 @@ struct StepLane {
         // reciprocal per column instead of one IEEE division per value): <= 1 ulp from the quotient
         const float inv = tb_rcpf(hi - lo + 1e-6f);
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-          const int n = g + G * i;
-          Lf[T.b_xn[c] + (n < T.N ? n : T.N - 1)] = (nfe[i][c] - lo) * inv;
-        }
+        for (int i = 0; i < NPL; ++i) nv[i][c] = (nfe[i][c] - lo) * inv;
+      }
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = g + G * i;
+        const int nc = n < T.N ? n : T.N - 1;
+        const tb_f4 a = {nv[i][0], nv[i][1], nv[i][2], nv[i][3]}, b = {nv[i][4], nv[i][5], nv[i][6], nv[i][7]};
+        ((tb_f4 *)(Lf + T.b_nna))[nc] = a;
+        ((tb_f4 *)(Lf + T.b_nnb))[nc] = b;
+        Lf[T.b_nn8 + nc] = nv[i][8];
       }
     }
   }
@@ -1379,33 +1382,19 @@ struct StepLane {
       }
     }
   }
-  // nN_x_e: the same with its table in LDS
-  TRUSS_HD void emit_nxe(const TopoDev &T, const StepArgsDev &A) const {
-    if (!A.nxe) return;
-    const float *Lf = (const float *)L;
-    const tb_u2 *tab = TB_TAB(tb_u2, TB, T.f_tnxe);
-    tb_f4 *o4 = (tb_f4 *)(A.nxe + (size_t)env * 21 * T.E);
+  // the nN_x_e table sits in LDS (staged with the topology tables); the streaming wave copies its entries to registers
+  // while it waits for the node bank: one LDS round trip less per batch of the last, exposed segment
+  TRUSS_HD void obs_nxe_table(const TopoDev &T) {
+    if constexpr (EMIT) {
+      const tb_u2 *tab = TB_TAB(tb_u2, TB, T.f_tnxe);
 #pragma unroll
-    for (int b0 = 0; b0 < IE; b0 += KB) {
-      if (b0 * G < T.nc_nxe) {
-        tb_u2 t[KB];
-        tb_f4 v[KB];
-#pragma unroll
-        for (int k = 0; k < KB; ++k)
-          if (b0 + k < IE) t[k] = tab[(b0 + k) * G + g];
-#pragma unroll
-        for (int k = 0; k < KB; ++k)
-          if (b0 + k < IE) v[k] = gather4(Lf, t[k]);
-#pragma unroll
-        for (int k = 0; k < KB; ++k)
-          if (b0 + k < IE) TB_STREAM_STORE(&o4[chunk_of(b0 + k, T.nc_nxe)], v[k]);
-      }
+      for (int i = 0; i < IE; ++i) ete[i] = tab[i * G + g];
     }
   }
   TRUSS_HD void obs_emit_raw_rows(const TopoDev &T, const StepArgsDev &A) {
     if constexpr (EMIT) {
       if (!active) return;
-      emit_nxe(T, A);
+      emit_rows<IE>(A.nxe, (size_t)21 * T.E, T.nc_nxe, ete);
       emit_rows<IN_>(A.nxn, (size_t)12 * T.N, T.nc_nxn, etn);
     }
   }
@@ -1432,7 +1421,9 @@ struct StepLane {
 // The streaming wave's work per progress value (PH as above).  HIP: the second wavefront of an EMIT workgroup runs
 // segment k once the compute wave has published k; emulator: EMIT_POINT(k, ...) runs segment k in place.
 #define TRUSS_STREAM_SEG1(PH, T, A) PH(obs_emit_as(T, A));
-#define TRUSS_STREAM_SEG2(PH, T, A) PH(obs_emit_tc(T, A));
+#define TRUSS_STREAM_SEG2(PH, T, A) \
+  PH(obs_emit_tc(T, A));            \
+  PH(obs_nxe_table(T));
 #define TRUSS_STREAM_SEG3(PH, T, A) \
   PH(obs_emit_raw_rows(T, A));      \
   PH(obs_emit_xn(T, A));
@@ -1445,7 +1436,7 @@ struct StepLane {
   TRUSS_ST(2);                                                                      \
   PH(phase_sizing(T, A));                                                           \
   if ((T).n_sym_elems > 0 && !((A).flags & TB_NO_DECODE)) { PH(phase_sym_elems(T)); } \
-  if (EMIT_) { EMIT_POINT(1); } /* compile-time; the sections are final */           \
+  if (EMIT_) { EMIT_POINT(1); TRUSS_ST(19); } /* compile-time; the sections are final */ \
   TRUSS_ST(3);                                                                      \
   PH(phase_elements(T, A));                                                         \
   TRUSS_ST(10);                                                                     \
@@ -1587,19 +1578,23 @@ struct StepLane {
   if (EMIT_) {                                                                      \
     PH(obs_elements_bank(T, A));                                                    \
     EMIT_POINT(2);                                                                  \
+    TRUSS_ST(18);                                                                   \
   }                                                                                 \
   TRUSS_ST(7);                                                                      \
   PH(phase_post_nodes(T, A));                                                       \
   TRUSS_ST(8);                                                                      \
+  if (EMIT_) { /* compile-time: the node part of the bank first, so that the streaming wave starts on the rows while   \
+                  this wave issues the step's own result stores (they queue behind the observation stream anyway) */  \
+    TRUSS_ST(15);                                                                   \
+    PH(obs_nodes_raw(T, A));                                                        \
+    TRUSS_ST(16);                                                                   \
+    PH(obs_bank_fill(T, A));                                                        \
+    EMIT_POINT(3);                                                                  \
+    TRUSS_ST(17);                                                                   \
+  }                                                                                 \
   PH_NS(phase_finish(T, A));                                                        \
   TRUSS_ST(12);                                                                     \
   PH_NS(phase_store(T, A));                                                         \
-  if (EMIT_) {                                                                      \
-    BAR(); /* the node part of the bank reuses solver scratch the nodal phases have just read */ \
-    PH(obs_nodes_raw(T, A));                                                        \
-    PH(obs_bank_fill(T, A));                                                        \
-    EMIT_POINT(3);                                                                  \
-  }                                                                                 \
   TRUSS_ST(9);
 
 // ================================================================================================

@@ -81,7 +81,7 @@ __device__ __forceinline__ float tb_rcpf(float d) {
 #ifdef TRUSS_STAMPS
 // Diagnostic build only (make diag): lane 0 of one mid-grid workgroup records s_memtime at the phase
 // boundaries into a buffer nothing else reads.  Never enabled in libtruss_mi355.so.
-__device__ unsigned long long g_truss_stamps[24];
+__device__ unsigned long long g_truss_stamps[32];
 // g_truss_span: every workgroup's first and last stamp as (shader clock, 100 MHz wall clock): spread of
 // the workgroups over the launch, effective shader frequency (tools/span.py).
 __device__ unsigned long long g_truss_span[4096][4];
@@ -89,7 +89,7 @@ __device__ unsigned long long g_truss_span[4096][4];
   do {                                                               \
     __builtin_amdgcn_sched_barrier(0);                               \
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_truss_stamps[i] = clock64(); \
-    if (threadIdx.x == 0 && ((i) == 0 || (i) == (EMIT_ ? 18 : 9)) && blockIdx.x < 4096) {              \
+    if (threadIdx.x == 0 && ((i) == 0 || (i) == 9) && blockIdx.x < 4096) {              \
       g_truss_span[blockIdx.x][(i) == 0 ? 0 : 2] = clock64();                            \
       g_truss_span[blockIdx.x][(i) == 0 ? 1 : 3] = wall_clock64();                       \
     }                                                                \
@@ -169,13 +169,34 @@ __global__ __launch_bounds__(EMIT ? 128 : 64) void truss_step_kernel(const TopoD
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
   __builtin_amdgcn_wave_barrier();                        \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+#ifdef TRUSS_STAMPS
+#define SST(i)                                                                                        \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (threadIdx.x == 64 && blockIdx.x == gridDim.x / 2) g_truss_stamps[i] = clock64();              \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#else
+#define SST(i)
+#endif
       ln.emit_tables_load(T);   // ahead of every store of this wave in the vmcnt order
       if (!tb_await(smem, T.o_flag, 1)) return;
+      SST(20);
       TRUSS_STREAM_SEG1(SPH, T, A)
+      SST(21);
       if (!tb_await(smem, T.o_flag, 2)) return;
+      SST(22);
       TRUSS_STREAM_SEG2(SPH, T, A)
+      SST(23);
       if (!tb_await(smem, T.o_flag, 3)) return;
+      SST(24);
       TRUSS_STREAM_SEG3(SPH, T, A)
+      SST(25);
+#ifdef TRUSS_STAMPS
+      __builtin_amdgcn_s_waitcnt(0);   // all stores of this wave retired (vmcnt(0))
+      SST(26);
+#endif
+#undef SST
 #undef SPH
       return;
     }
@@ -435,8 +456,8 @@ static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, 
 extern "C" int truss_debug_span(unsigned long long *out, int nblocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_truss_span), (size_t)nblocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
-extern "C" int truss_debug_stamps24(unsigned long long *out24) {
-  return hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_truss_stamps), 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+extern "C" int truss_debug_stamps32(unsigned long long *out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_truss_stamps), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 extern "C" int truss_debug_stamps(unsigned long long *out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_truss_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;

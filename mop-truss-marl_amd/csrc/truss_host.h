@@ -144,14 +144,9 @@ static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res
     }
     return true;
   };
-  if (!place({{&D.b_ev2, 2 * (E + 1)}, {&D.b_esec, E}, {&D.b_earea, E}, {&D.b_elen, E}, {&D.b_etens, E}, {&D.b_ecomp, E}, {&D.b_eviol, E},
-              {&D.b_const, 3}},   // the constants are written with the element part (progress 2)
-             early))
-    return false;
-  for (const TbFrag &f : early) late.push_back(f);   // what the element arrays left over
-  std::vector<Arr> nodes = {{&D.b_nload, N}, {&D.b_nt9, N}, {&D.b_nady, N}, {&D.b_nvge, N}};
-  for (int c = 0; c < 9; ++c) nodes.push_back({&D.b_xn[c], N});
-  if (!place(nodes, late)) return false;
+  if (!place({{&D.b_erec, 8 * (E + 1)}, {&D.b_const, 3}}, early)) return false;   // written with the member results
+  for (const TbFrag &f : early) late.push_back(f);                                   // what the element records left over
+  if (!place({{&D.b_nna, 4 * N}, {&D.b_nnb, 4 * N}, {&D.b_nraw, 4 * N}, {&D.b_nn8, N}}, late)) return false;
   if (D.env_stride / 4 > 65535 || E + 1 > 65535) return false;
   const int ZERO = D.b_const, ONE = D.b_const + 1, C1 = D.b_const + 2;
   const int fX = D.o_x / 4, fY = D.o_y / 4, fMU = (D.o_kb + D.so_mu) / 4, fMD = (D.o_kb + D.so_md) / 4,
@@ -165,18 +160,24 @@ static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res
   std::vector<uint16_t> txn, tnxn, tnxe, tmat;
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < 13; ++c)
-      txn.push_back((uint16_t)(dyn_of[c] >= 0 ? D.b_xn[dyn_of[c]] + n : (flag(n, c) && any0[c] ? C1 : ZERO)));
+      txn.push_back((uint16_t)(dyn_of[c] < 0   ? (flag(n, c) && any0[c] ? C1 : ZERO)
+                               : dyn_of[c] < 4 ? D.b_nna + 4 * n + dyn_of[c]
+                               : dyn_of[c] < 8 ? D.b_nnb + 4 * n + dyn_of[c] - 4
+                                               : D.b_nn8 + n));
   for (int n = 0; n < N; ++n) {
-    const int src[12] = {fX + n, fY + n, res[2 * n] ? ONE : ZERO, res[2 * n + 1] ? ONE : ZERO, D.b_nload + n, top[n] ? ONE : ZERO,
-                         top[n] ? ZERO : ONE, fMU + n, fMD + n, D.b_nt9 + n, D.b_nady + n, D.b_nvge + n};
+    const int nr = D.b_nraw + 4 * n;   // loaded, target / y, |dy|, violated
+    const int src[12] = {fX + n, fY + n, res[2 * n] ? ONE : ZERO, res[2 * n + 1] ? ONE : ZERO, nr + 0, top[n] ? ONE : ZERO,
+                         top[n] ? ZERO : ONE, fMU + n, fMD + n, nr + 1, nr + 2, nr + 3};
     for (int c = 0; c < 12; ++c) tnxn.push_back((uint16_t)src[c]);
   }
   for (int e = 0; e < E; ++e) {
-    const int own[7] = {D.b_esec + e, D.b_earea + e, D.b_elen + e, D.b_etens + e, D.b_ecomp + e, fQ0 + e, D.b_eviol + e};
+    const int er = D.b_erec + 8 * e;   // sec, area, length, tension, compression, violated, (A_n_ts, A_n_cs)
+    const int own[7] = {er + 0, er + 1, er + 2, er + 3, er + 4, fQ0 + e, er + 5};
     for (int c = 0; c < 7; ++c) tnxe.push_back((uint16_t)own[c]);
     for (int q = 0; q < 2; ++q) {
       const int n = conn[2 * e + q];
-      const int nd[7] = {fX + n, fY + n, res[2 * n] ? ONE : ZERO, res[2 * n + 1] ? ONE : ZERO, D.b_nload + n, D.b_nady + n, D.b_nvge + n};
+      const int nr = D.b_nraw + 4 * n;
+      const int nd[7] = {fX + n, fY + n, res[2 * n] ? ONE : ZERO, res[2 * n + 1] ? ONE : ZERO, nr + 0, nr + 2, nr + 3};
       for (int c = 0; c < 7; ++c) tnxe.push_back((uint16_t)nd[c]);
     }
   }

@@ -21,6 +21,14 @@ def rank_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def shard_bounds(global_envs, world, rank):
+    """Contiguous split of a global env batch over the ranks: [lo, hi) of this rank; the first
+    `global_envs % world` ranks take one env more."""
+    q, r = divmod(int(global_envs), int(world))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
 def make_rank_env(topo, envs_per_rank, rank, device=None, lib=None, seed=1234, n_action_sets=8, debug_f64=False):
     """Resident state of this rank's shard: env batch + a pool of pre-drawn action sets."""
     batch = synthetic.random_batch(topo, envs_per_rank, seed=seed + 7919 * rank)

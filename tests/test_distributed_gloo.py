@@ -113,3 +113,40 @@ def test_two_rank_data_parallel_marl():
         assert p.exitcode == 0
     assert replay >= 4 and steps >= 15
     np.testing.assert_allclose(sigs[0], sigs[1], rtol=1e-12)
+
+
+def _bench_line(extra_args, extra_env=None):
+    """bench.py started the way the driver starts it for one GPU (`python bench.py --gpus N ...`, no launcher): it has
+    to spawn its own ranks.  CPU rehearsal: gloo + the lane emulator."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(TRUSS_BENCH_BACKEND="gloo", TRUSS_BENCH_STRONG="12,21", **(extra_env or {}))
+    r = subprocess.run([sys.executable, os.path.join(pc.ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--lib", pc.build_emu()] + extra_args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]       # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks_weak_and_strong():
+    o = _bench_line(["--gpus", "2", "--envs", "8"])
+    assert o["n_gpus"] == 2 and o["scaling"] == "weak" and o["timed_blocks"] >= 5
+    assert o["config"]["envs_per_gpu"] == 8 and o["config"]["global_envs"] == 16
+    assert o["ms_per_step_min"] <= o["ms_per_step"] <= o["ms_per_step_max"]
+    assert abs(o["value"] - 16 / (o["ms_per_step"] * 1e-3)) < 1e-6 * o["value"]
+    # the strong-scaling legs ride along: contiguous split of a fixed global batch (SURVEY.md §8e)
+    assert o["strong"]["global_envs_12"]["envs_per_gpu"] == 6 and o["strong"]["global_envs_21"]["envs_per_gpu"] == 11
+    s = _bench_line(["--gpus", "2", "--scaling", "strong", "--global-envs", "11"])
+    assert s["scaling"] == "strong" and s["config"]["global_envs"] == 11 and s["config"]["envs_per_gpu"] == 6
+    assert abs(s["value"] - 11 / (s["ms_per_step"] * 1e-3)) < 1e-6 * s["value"]
+
+
+def test_shard_bounds_cover_the_batch():
+    from truss_mi355 import distributed
+    for ge, world in ((4096, 8), (8192, 8), (11, 2), (5, 8), (4097, 3)):
+        b = [distributed.shard_bounds(ge, world, r) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == ge and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1

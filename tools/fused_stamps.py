@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: cycles per phase of one workgroup of the FUSED step (TRUSS_F_EMIT_OBS), stamped build
-(make -C mop-truss-marl_amd/csrc diag).  Shares only -- the stamped build's run time is not a benchmark number."""
+"""Diagnostic: timeline of one workgroup of the FUSED step (TRUSS_F_EMIT_OBS): compute wave phases and progress
+publications, streaming wave segments.  Stamped build (make -C mop-truss-marl_amd/csrc diag); the stamped build's
+run time is not a benchmark number."""
 import ctypes
 import os
 import sys
@@ -15,7 +16,7 @@ from truss_mi355 import synthetic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 path = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "mop-truss-marl_amd", "csrc", "libtruss_mi355_diag.so")
 lib = tm.load(path)
-lib.dll.truss_debug_stamps24.argtypes = [ctypes.c_void_p]
+lib.dll.truss_debug_stamps32.argtypes = [ctypes.c_void_p]
 topo = synthetic.bench_topology(16, 4)
 batch = synthetic.random_batch(topo, B, 1)
 env = tm.BatchedTruss(topo, B, lib=lib)
@@ -28,25 +29,25 @@ ob = env.obs_buffers()
 for _ in range(20):
     env.step(G, T, obs=ob)
 torch.cuda.synchronize()
-# order of the stamps along the schedule
-ORDER = [0, 1, 2, 3, 10, 11, 4, 13, 5, 14, 6, 7, 8, 12, 9, 15, 16, 17, 18]
-NAMES = ["stage", "decode", "sizing", "elements", "assemble_nodes", "scratch_init", "factor clean", "factor merge+check",
-         "backsub handover", "backsub clean", "post_elements", "post_nodes", "finish", "store rows", "(barrier)",
-         "obs nodes raw", "obs bank fill", "obs emit"]
-acc = np.zeros(len(ORDER) - 1)
-for _ in range(10):
+EVENTS = [(0, "C start"), (1, "C staged"), (19, "C publish 1 (sections final)"), (4, "C solver starts"), (6, "C solver done"),
+          (18, "C publish 2 (element bank)"), (8, "C post_nodes done"), (15, "C own stores issued"), (16, "C raw node features done"),
+          (17, "C publish 3 (node bank)"), (9, "C end"),
+          (20, "S seg1 start (A_s)"), (21, "S seg1 issued"), (22, "S seg2 start (A_n_ts/cs)"), (23, "S seg2 issued"),
+          (24, "S seg3 start (rows)"), (25, "S seg3 issued"), (26, "S all stores retired")]
+acc = np.zeros(len(EVENTS))
+N = 10
+for _ in range(N):
     env.step(G, T, obs=ob)
     torch.cuda.synchronize()
-    st = (ctypes.c_ulonglong * 24)()
-    lib.dll.truss_debug_stamps24(st)
-    s = np.array([st[i] for i in ORDER], dtype=np.float64)
-    acc += np.diff(s)
-acc /= 10
+    st = (ctypes.c_ulonglong * 32)()
+    lib.dll.truss_debug_stamps32(st)
+    acc += np.array([float(st[i]) - float(st[0]) for i, _ in EVENTS])
+acc /= N
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(100):
     env.step(G, T, obs=ob)
 e1.record(); torch.cuda.synchronize()
-print(f"fused={env.fused_obs} B={B} total {acc.sum():.0f} cycles; stamped launch {e0.elapsed_time(e1) * 10:.2f} us")
-for n, c in zip(NAMES, acc):
-    print(f"   {n:22s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f} %")
+print(f"fused={env.fused_obs} B={B}; stamped launch {e0.elapsed_time(e1) * 10:.2f} us; cycles since the compute wave's start (mid-grid workgroup)")
+for (i, n), c in sorted(zip(EVENTS, acc), key=lambda t: t[1]):
+    print(f"   {c:9.0f}  {n}")

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py.
+# Run ON THE GPU BOX (via gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py (plain step kernel and
+# the fused state-emitting step both run in a default bench.py invocation).
 # Summaries land in gpurun_out/prof/ ; copy the ones to be judged into profiles/rN/.
 #   gpurun --timeout 900 -- 'bash tools/profile_round.sh'
 set -o pipefail
@@ -13,8 +14,9 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE
   tag=$(echo $c | tr ' ' '+')
   timeout -k 10 200 rocprofv3 --pmc $c -d $OUT/pmc_$tag -o pmc -- $B --steps 20 --warmup 2 > /dev/null 2> $OUT/pmc_$tag.err || { echo "pmc pass $c failed"; tail -3 $OUT/pmc_$tag.err; }
 done
-timeout -k 10 100 $B --extras > $OUT/bench_plain.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --extras > $OUT/bench_plain.json 2>/dev/null
 python3 tools/reduce_profile.py $OUT > $OUT/summary.json
-cat $OUT/summary.json
+head -c 3000 $OUT/summary.json
 # keep only the small files
 find $OUT -name "*.csv" -size +2M -delete
+find $OUT -name "*.db" -size +8M -delete

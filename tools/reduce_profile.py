@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Reduce the rocprofv3 output of tools/profile_round.sh (rocpd SQLite databases) to one JSON summary:
-per-kernel statistics of the --kernel-trace pass, per-dispatch medians of every PMC counter for the step
-kernel, and the HBM bytes per launch with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md."""
+per-kernel statistics of the --kernel-trace pass, per-dispatch medians of every PMC counter for each step-kernel
+instantiation (plain / with the fused observation writer), and the HBM bytes per launch with the gfx950
+FETCH_SIZE correction of MI355X_MICROARCH.md.  Also writes <out>/pmc_traffic.json, which bench.py reads for
+`roofline.traffic` (tagged with the hash of the kernel source it was measured on)."""
 import glob
+import hashlib
 import json
 import os
 import sqlite3
@@ -10,13 +13,16 @@ import statistics
 import sys
 
 out = sys.argv[1]
-res = {"kernel_stats": [], "pmc": {}}
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+res = {"kernel_stats": [], "pmc": {}, "dispatch": {}}
 for f in glob.glob(os.path.join(out, "kt", "**", "*.db"), recursive=True):
     c = sqlite3.connect(f)
     for name, in c.execute("select distinct name from kernels where name like '%truss%'"):
         d = [r[0] / 1e3 for r in c.execute("select duration from kernels where name = ?", (name,))]
+        g = c.execute("select grid_x, workgroup_x, lds_size from kernels where name = ? limit 1", (name,)).fetchone()
         res["kernel_stats"].append({"name": name, "calls": len(d), "average_us": statistics.mean(d), "median_us": statistics.median(d),
-                                    "min_us": min(d), "max_us": max(d), "stdev_us": statistics.pstdev(d)})
+                                    "min_us": min(d), "max_us": max(d), "stdev_us": statistics.pstdev(d),
+                                    "grid": g[0], "workgroup": g[1], "lds_bytes": g[2]})
     tot = c.execute("select sum(duration) from kernels").fetchone()[0]
     for k in res["kernel_stats"]:
         k["share_of_gpu_time"] = k["average_us"] * k["calls"] * 1e3 / tot
@@ -26,21 +32,32 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True):
     q = ("select counter_name, value, kernel_name, grid_size, workgroup_size, lds_block_size, scratch_size, vgpr_count, "
          "accum_vgpr_count, sgpr_count from counters_collection where kernel_name like '%truss_step_kernel%'")
     for cn, v, kn, gs, ws, lds, scr, vg, ag, sg in c.execute(q):
-        vals.setdefault(cn, []).append(float(v))
-        res.setdefault("dispatch", {"kernel": kn, "grid": gs, "workgroup": ws, "lds_bytes": lds, "scratch": scr, "vgpr": vg,
-                                    "accum_vgpr": ag, "sgpr": sg})
-    for k, v in vals.items():
-        res["pmc"][k] = {"n_dispatches": len(v), "median": statistics.median(v), "min": min(v), "max": max(v)}
-p = res["pmc"]
-if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
-    rd = p["FETCH_SIZE"]["median"] * 1024 * 2      # KB -> B, x2: gfx950 tallies 128-B requests at 64 B
-    wr = p["WRITE_SIZE"]["median"] * 1024
-    res["hbm_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr,
-                                   "note": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes; FETCH_SIZE x2 (gfx950 correction)"}
+        if gs // ws != 1024:          # the 4096-env launches only (16 lanes per env: 1024 workgroups)
+            continue
+        vals.setdefault(kn, {}).setdefault(cn, []).append(float(v))
+        res["dispatch"].setdefault(kn, {"grid": gs, "workgroup": ws, "lds_bytes": lds, "scratch": scr, "vgpr": vg, "accum_vgpr": ag, "sgpr": sg})
+    for kn, d in vals.items():
+        for k, v in d.items():
+            res["pmc"].setdefault(kn, {})[k] = {"n_dispatches": len(v), "median": statistics.median(v), "min": min(v), "max": max(v)}
+res["hbm_bytes_per_launch"] = {}
+for kn, p in res["pmc"].items():
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        rd = p["FETCH_SIZE"]["median"] * 1024 * 2      # KB -> B, x2: gfx950 tallies 128-B requests at 64 B
+        wr = p["WRITE_SIZE"]["median"] * 1024
+        res["hbm_bytes_per_launch"][kn] = {"read_corrected": rd, "write": wr, "total": rd + wr}
+res["hbm_bytes_note"] = "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes; FETCH_SIZE x2 (gfx950 correction)"
 for name in ("bench_under_trace.json", "bench_plain.json"):
     try:
         line = [l for l in open(os.path.join(out, name)) if l.startswith("{")][-1]
         res[name[:-5]] = json.loads(line)
     except Exception as e:  # noqa: BLE001
         res[name[:-5]] = f"unavailable: {e}"
+src = open(os.path.join(root, "mop-truss-marl_amd", "csrc", "truss_body.h"), "rb").read()
+plain = [v for k, v in res["hbm_bytes_per_launch"].items() if "false" in k]
+fused = [v for k, v in res["hbm_bytes_per_launch"].items() if "true" in k]
+json.dump({"envs": 4096, "nodes": 32, "elements": 80, "truss_body_sha16": hashlib.sha256(src).hexdigest()[:16],
+           "step_kernel_bytes_per_launch": plain[0]["total"] if plain else None,
+           "fused_step_kernel_bytes_per_launch": fused[0]["total"] if fused else None,
+           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x 2 (gfx950), median over dispatches"},
+          open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
