@@ -826,7 +826,6 @@ struct StepLane {
   double nc[RPL][W], nz[RPL], nd[RPL];   // ... in the next block (in flight); nd = the pivot d itself
   double bx;                             // this lane's candidate for x_k (valid in the owner lane)
   double myx[RPL] = {};                  // x of the rows this lane owns in the current block
-  StepLane *peers = nullptr;             // emulator only: the 64 lanes of the wave (DPP stand-in)
   TRUSS_HD void backsub_rows_fetch(const TopoDev &T, int kb) {
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {

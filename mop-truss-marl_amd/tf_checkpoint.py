@@ -184,7 +184,6 @@ def load_gcn_actor(actor, prefix, verify=True):
             dev = layer.bias.device
             layer.lin = lin.to(dev)
             layer.bias.copy_(torch.from_numpy(b).to(dev))
-        layer._init = True                                # no Glorot re-initialisation on the first call
         n += k.size + b.size
     missing = [m for m, _ in actor.named_children() if m.startswith("gcn_") and m not in names]
     if missing:

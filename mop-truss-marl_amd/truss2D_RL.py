@@ -52,13 +52,15 @@ class GCNConv(nn.Module):
         super().__init__()
         self.lin = nn.LazyLinear(channels, bias=False)
         self.bias = nn.Parameter(torch.zeros(channels))
-        self._init = False
 
     def forward(self, x, a):
+        # GlorotNormal exactly once: when this call materialises the lazy kernel.  A kernel that came in through
+        # load_state_dict / the TensorFlow reader is already materialised and is left alone (a flag on the module is
+        # not part of the state_dict: restored kernels were re-initialised on their first forward).
+        fresh = isinstance(self.lin.weight, nn.parameter.UninitializedParameter)
         h = self.lin(x)
-        if not self._init:
+        if fresh:
             nn.init.xavier_normal_(self.lin.weight)
-            self._init = True
             h = self.lin(x)
         return torch.matmul(a, h) + self.bias
 

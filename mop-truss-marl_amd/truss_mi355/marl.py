@@ -86,7 +86,7 @@ def actor_infer(lib, actor, ins):
     x_n, A_n, A_s, A_ts, A_cs, x_p, A_p = ins
 
     def g(layer, x, a, act="relu"):
-        if not layer._init:                       # lazy layers: let the module materialise itself once
+        if isinstance(layer.lin.weight, torch.nn.parameter.UninitializedParameter):   # lazy layers: let the module materialise itself once
             with torch.no_grad():
                 layer(x[:1], a[:1] if a.dim() == 3 else a)
         return gcn_aggregate(lib, a, layer.lin(x).contiguous(), layer.bias, act)
@@ -266,6 +266,7 @@ class BatchedMARL:
                 had_state = [bool(ag_.critic_opt.state) for ag_ in self.rl.agents]
                 osnap = [{id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
                           for p, st in ag_.critic_opt.state.items()} for ag_ in self.rl.agents]
+                n_loss = [len(ag_.c_loss) for ag_ in self.rl.agents]
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
@@ -273,22 +274,27 @@ class BatchedMARL:
                         self.rl.train_on_batch(*unpack(bufs))
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 torch.cuda.synchronize(self.device)
+                def restore():      # weights, Adam moments and loss log back to the state before the warm-up
+                    with torch.no_grad():
+                        for n, sp in zip(nets, snap):
+                            for p, v in zip(n.parameters(), sp):
+                                p.copy_(v)
+                        for ag_, had, sn in zip(self.rl.agents, had_state, osnap):
+                            for p, st in ag_.critic_opt.state.items():
+                                for k, v in st.items():
+                                    if torch.is_tensor(v):
+                                        v.copy_(sn[id(p)][k]) if had else v.zero_()
+                    for ag_, nl in zip(self.rl.agents, n_loss):
+                        del ag_.c_loss[nl:]
+
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    self.rl.train_on_batch(*unpack(bufs))
-                with torch.no_grad():
-                    for n, sp in zip(nets, snap):
-                        for p, v in zip(n.parameters(), sp):
-                            p.copy_(v)
-                    for ag_, had, sn in zip(self.rl.agents, had_state, osnap):
-                        for p, st in ag_.critic_opt.state.items():
-                            for k, v in st.items():
-                                if torch.is_tensor(v):
-                                    v.copy_(sn[id(p)][k]) if had else v.zero_()
-                for ag_ in self.rl.agents:
-                    del ag_.c_loss[-4:]                                  # the warm-up / capture entries
+                try:
+                    with torch.cuda.graph(g, stream=side):
+                        self.rl.train_on_batch(*unpack(bufs))
+                finally:
+                    restore()       # captured or not: training continues from the pre-warm-up state
                 self._tg = (g, bufs)
-            except Exception as e:                                       # capture is an optimisation, never a requirement
+            except RuntimeError as e:                                    # capture is an optimisation, never a requirement
                 print(f"[marl] hipGraph capture of the MADDPG update failed ({type(e).__name__}: {e}); running eagerly")
                 self.use_train_graph = False
                 torch.cuda.synchronize(self.device)

@@ -20,22 +20,29 @@ struct float4 {
 #define TB_STREAM_STORE(p, v) (*(p) = (v))
 static inline void tb_lds_add(double *p, double v) { *p += v; }
 static inline double tb_rcp(double d) { return 1.0 / d; }
+// The emulator's lanes know their wave (cross-lane stand-ins below); the product's lane struct does not.
+template <class LN>
+struct EmuLane : LN {
+  EmuLane *peers = nullptr;   // the 64 lanes of the workgroup
+};
+template <class LN>
+static inline EmuLane<LN> *emu_peers(LN &ln) { return static_cast<EmuLane<LN> &>(ln).peers; }
 // DPP row broadcast stand-in: the value lane `src` of this lane's team computed in the previous phase
 template <class LN>
-static inline double tb_team_bcast(LN &ln, int src) { return ln.peers[ln.lane - ln.gs + src].bx; }
+static inline double tb_team_bcast(LN &ln, int src) { return emu_peers(ln)[ln.lane - ln.gs + src].bx; }
 static inline double tb_rsqrt(double x) { return 1.0 / sqrt(x); }
 static inline float tb_rcpf(float d) { return 1.0f / d; }
 // min / max over the lanes of an env: the partials the lanes left in the previous phase
 template <class LN>
 static inline float tb_group_min(LN &ln, int c) {
   float v = INFINITY;
-  for (int j = 0; j < LN::G_; ++j) v = fminf(v, ln.peers[ln.lane - ln.g + j].pmn[c]);
+  for (int j = 0; j < LN::G_; ++j) v = fminf(v, emu_peers(ln)[ln.lane - ln.g + j].pmn[c]);
   return v;
 }
 template <class LN>
 static inline float tb_group_max(LN &ln, int c) {
   float v = -INFINITY;
-  for (int j = 0; j < LN::G_; ++j) v = fmaxf(v, ln.peers[ln.lane - ln.g + j].pmx[c]);
+  for (int j = 0; j < LN::G_; ++j) v = fmaxf(v, emu_peers(ln)[ln.lane - ln.g + j].pmx[c]);
   return v;
 }
 
@@ -56,7 +63,7 @@ static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream)
 
 template <int G, int WL, int RPL, int EPL, bool EMIT>
 static void emu_run(const truss_topo *t, const StepArgsDev &A) {
-  using Lane = StepLane<G, WL, RPL, EPL, EMIT>;
+  using Lane = EmuLane<StepLane<G, WL, RPL, EPL, EMIT>>;
   constexpr int W_ = Lane::W;
   constexpr bool EMIT_ = EMIT;
   const TopoDev &T = EMIT ? t->dev_emit : t->dev;

@@ -74,6 +74,63 @@ def test_actor_critic_shapes_and_quirks():
     np.testing.assert_allclose(out.detach().numpy(), (A @ (X @ conv.lin.weight.T) + conv.bias).detach().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_actor_critic_survive_a_state_dict_round_trip():
+    """A restored kernel must not be re-initialised by the first forward (round-1 bug: the Glorot flag of GCNConv
+    was a plain attribute, not part of the state_dict)."""
+    import truss2D_RL as RL
+    torch.manual_seed(1)
+    B, N, P = 3, 12, 20
+    ins = [torch.rand(B, N, 13), torch.rand(B, N, N), torch.rand(B, N, N), torch.rand(B, N, N), torch.rand(B, N, N),
+           torch.rand(B, P, 4), torch.rand(B, P, P)]
+    actor = RL.multimodes_actor(16, 2, 3)
+    g, t = actor(ins)
+    critic = RL.multimodes_critic(16, 8)
+    cin = ins[:5] + [torch.rand(B, N, N)] + ins[5:] + [g, t, g, t, g, t]
+    q = critic(cin)
+    a2, c2 = RL.multimodes_actor(16, 2, 3), RL.multimodes_critic(16, 8)      # fresh: lazy kernels not yet materialised
+    a2.load_state_dict(actor.state_dict())
+    c2.load_state_dict(critic.state_dict())
+    g2, t2 = a2(ins)
+    assert torch.equal(g, g2) and torch.equal(t, t2) and torch.equal(q, c2(cin))
+    for (k, v), (k2, v2) in zip(actor.state_dict().items(), a2.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2), k
+
+
+def test_maddpg_save_load_weights_round_trip(tmp_path):
+    """MADDPG.save_weights -> load_weights into a NEW trainer (master_DDPG_truss2D_MO.main() with base_num != 0,
+    master…:710-733): actors, critics and both target nets give the saved model's outputs."""
+    import truss2D_RL as RL
+    torch.manual_seed(2)
+    N, P = 12, 20
+
+    import master_DDPG_truss2D_MO as M
+
+    def make():
+        return RL.MADDPG(M.lr, M.ep, M.epd, M.gamma, 16, 16, 100, M.num_agents, M.num_action, M.mu, M.theta, M.sigma, device="cpu")
+
+    m1 = make()
+    ins = [torch.rand(1, N, 13), torch.rand(1, N, N), torch.rand(1, N, N), torch.rand(1, N, N), torch.rand(1, N, N),
+           torch.rand(1, P, 4), torch.rand(1, P, P)]
+    outs1 = [ag.actor_model(ins) for ag in m1.agents]
+    acts = [o for pair in outs1 for o in pair]
+    cin = ins[:5] + [torch.rand(1, N, N)] + ins[5:] + acts
+    q1 = [ag.critic_model(cin) for ag in m1.agents]
+    for ag in m1.agents:                      # materialise the targets too (update_init hard copy, RL:402-404)
+        ag.target_actor_model(ins)
+        ag.target_critic_model(cin)
+        ag.update_init()
+    prefix = str(tmp_path) + "/"
+    m1.save_weights(prefix)
+    m2 = make()
+    m2.load_weights(prefix)
+    for a1, a2_, (g1, t1), qa in zip(m1.agents, m2.agents, outs1, q1):
+        g2, t2 = a2_.actor_model(ins)
+        assert torch.equal(g1, g2) and torch.equal(t1, t2)
+        gt, tt = a2_.target_actor_model(ins)
+        assert torch.equal(g1, gt) and torch.equal(t1, tt)
+        assert torch.equal(qa, a2_.critic_model(cin)) and torch.equal(qa, a2_.target_critic_model(cin))
+
+
 def test_run_two_game_steps_emulated(tmp_path, monkeypatch):
     """One short game through run(): three agents act on every archived design, rewards are finite,
     the archive is a non-dominated feasible set, transitions reach the replay buffer and train() runs."""
