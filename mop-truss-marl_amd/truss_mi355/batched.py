@@ -4,7 +4,8 @@ This is the product-side host mirror of the reference's `Game_research04` transi
 (`_game_modify`, truss2D_ENV.py:370-525) and reset analysis (`_game_get_1_state`, :336-351) for a
 whole batch of environments.  PyTorch is used for device memory, streams and (in bench/training)
 torch.distributed only; all arithmetic happens in the native library behind the C ABI
-(include/truss_mi355.h).
+(include/truss_mi355.h), reached through the PyTorch custom operators `torch.ops.truss_mi355.*`
+(truss_mi355/ops.py, csrc/truss_torch_ops.cpp).
 
 Tensors live on the device that matches the loaded library's backend: "hip" -> a cuda device.
 """
@@ -15,7 +16,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .topology import TrussTopology
 
 
@@ -47,6 +48,8 @@ class BatchedTruss:
         if self.lib.backend == "hip" and self.device.type != "cuda":
             raise _lib.TrussError("the HIP library needs tensors on a cuda (ROCm) device")
         self.topo = topo
+        self._ops = ops.namespace()
+        self._lib_id = ops.bind(self.lib)
         # the native topology owns device tables: one handle per (library, device), created on THIS device
         with self._on_device():
             self.h = topo.native(self.lib, self.device.index if self.device.type == "cuda" else None)
@@ -79,8 +82,6 @@ class BatchedTruss:
         self.disp_f64 = z((B, N, 2), f64) if debug_f64 else None
         self.q0_f64 = z((B, E), f64) if debug_f64 else None
         self._coin0 = z((B,), u8)
-        self._step_cache = {}
-        self._obs_cache = {}
 
     # current design
     @property
@@ -135,28 +136,21 @@ class BatchedTruss:
         """True when step(obs=...) writes the observations from the step's own launch for this topology."""
         return bool(self.lib.dll.truss_topo_fused_obs(self.h))
 
-    def _args(self, flags, a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy=True, n_envs=None,
-              obs=None):
-        a = _lib.StepArgs()
-        a.struct_size = C.sizeof(_lib.StepArgs)
-        a.n_envs, a.flags = (self.B if n_envs is None else int(n_envs)), flags
-        a.x, a.y_in, a.sec_in = _ptr(self.x), _ptr(y_in), _ptr(sec_in)
-        a.max_up_in, a.max_down_in = _ptr(mu_in), _ptr(md_in)
-        a.a_geo, a.a_topo, a.coin = _ptr(a_geo), _ptr(a_topo), _ptr(coin)
-        a.target, a.env_params = _ptr(self.target), _ptr(self.env_params)
-        a.y_out, a.sec_out = _ptr(y_out), _ptr(sec_out)
-        a.max_up_out, a.max_down_out = _ptr(self.max_up), _ptr(self.max_down)
-        a.disp, a.q0, a.sr, a.comp = _ptr(self.disp), _ptr(self.q0), _ptr(self.sr), _ptr(self.comp)
-        a.point, a.obj = _ptr(self.point), _ptr(self.obj)
-        a.disp_f64, a.q0_f64 = _ptr(self.disp_f64), _ptr(self.q0_f64)
-        a.energy = _ptr(self.energy) if want_energy else None
-        a.reactions = _ptr(self.reactions) if want_energy else None
-        a.status = _ptr(self.status)
+    def _step_tensors(self, a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy, obs):
+        o = obs or {}
+        return (self.x, y_in, sec_in, mu_in, md_in, a_geo, a_topo, coin, self.target, self.env_params, y_out, sec_out,
+                self.max_up, self.max_down, self.disp, self.q0, self.sr, self.comp, self.point, self.obj, self.disp_f64,
+                self.q0_f64, self.energy if want_energy else None, self.reactions if want_energy else None, self.status,
+                o.get("x_n"), o.get("A_s"), o.get("A_n_ts"), o.get("A_n_cs"), o.get("nN_x_n"), o.get("nN_x_e"))
+
+    def _step_op(self, flags, n_envs, a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy=True,
+                 obs=None):
+        """torch.ops.truss_mi355.step: one truss_step launch (+ the observation tensors with `obs`)."""
         if obs is not None:
-            a.flags |= _lib.F_EMIT_OBS
-            a.x_n, a.A_s, a.A_n_ts, a.A_n_cs = (_ptr(obs.get(k)) for k in ("x_n", "A_s", "A_n_ts", "A_n_cs"))
-            a.nN_x_n, a.nN_x_e = _ptr(obs.get("nN_x_n")), _ptr(obs.get("nN_x_e"))
-        return a
+            flags |= _lib.F_EMIT_OBS
+        with self._on_device():
+            ops.call(self._ops.step, self._lib_id, self.h.value, ops.stream_of(self.device), flags, n_envs, self.N, self.E,
+                           *self._step_tensors(a_geo, a_topo, coin, mu_in, md_in, y_in, sec_in, y_out, sec_out, want_energy, obs))
 
     def _chk(self, t, shape, dtype, name):
         if t is None:
@@ -203,10 +197,7 @@ class BatchedTruss:
         if n == 0:
             return None
         out = None if obs is None or obs is False else self._obs_out(obs, n)
-        a = self._args(_lib.F_NO_DECODE, None, None, None, None, None, self.y, self.sec, self.y, self.sec,
-                       n_envs=n, obs=out)
-        with self._on_device():
-            self.lib.check(self.lib.dll.truss_step(self.h, C.byref(a), self._stream()), "truss_step(analyze)")
+        self._step_op(_lib.F_NO_DECODE, n, None, None, None, None, None, self.y, self.sec, self.y, self.sec, obs=out)
         if set_normalisers:
             self.env_params[:, _lib.P_INTOBJ1] = self.obj[:, 0].double()
             self.env_params[:, _lib.P_INTOBJ2] = self.obj[:, 1].double()
@@ -230,28 +221,16 @@ class BatchedTruss:
             coin = self._coin0
         nxt = self.cur ^ 1
         flags = _lib.F_CLAMP_INPLACE if clamp_inplace else 0
-        # an RL loop passes the same buffers every step: validated argument blocks are kept per buffer set
-        key = (self.cur, flags, a_geo.data_ptr(), a_topo.data_ptr(), coin.data_ptr(),
-               0 if max_up_in is None else max_up_in.data_ptr(), 0 if max_down_in is None else max_down_in.data_ptr(),
-               a_geo.shape, a_topo.shape, a_geo.dtype, a_topo.dtype, a_geo.is_contiguous(), a_topo.is_contiguous(), B,
-               None if out is None else tuple(0 if out.get(k) is None else out[k].data_ptr() for k in self.OBS_KEYS))
-        a = self._step_cache.get(key)
-        if a is None:
-            self._chk(a_geo, (B, N, 2), torch.float32, "a_geo")
-            self._chk(a_topo, (B, N, 3), torch.float32, "a_topo")
-            if coin is not self._coin0:
-                self._chk(coin, (B,), torch.uint8, "coin")
-            self._chk(max_up_in, (B, N), torch.float32, "max_up_in")
-            self._chk(max_down_in, (B, N), torch.float32, "max_down_in")
-            a = self._args(flags, a_geo, a_topo, coin, max_up_in, max_down_in, self.ybuf[self.cur], self.secbuf[self.cur],
-                           self.ybuf[nxt], self.secbuf[nxt], n_envs=B, obs=out)
-            if len(self._step_cache) > 64:
-                self._step_cache.clear()
-            self._step_cache[key] = a
-        with self._on_device():
-            rc = self.lib.dll.truss_step(self.h, C.byref(a), self._stream())
-        if rc:
-            self.lib.check(rc, "truss_step")
+        if tuple(a_geo.shape) != (B, N, 2) or tuple(a_topo.shape) != (B, N, 3):
+            raise ValueError(f"actions: expected [{B}, {N}, 2] and [{B}, {N}, 3], got {tuple(a_geo.shape)} and {tuple(a_topo.shape)}")
+        for t, nm in ((max_up_in, "max_up_in"), (max_down_in, "max_down_in")):
+            if t is not None and tuple(t.shape) != (B, N):
+                raise ValueError(f"{nm}: expected [{B}, {N}], got {tuple(t.shape)}")
+        if coin is not self._coin0 and tuple(coin.shape) != (B,):
+            raise ValueError(f"coin: expected [{B}], got {tuple(coin.shape)}")
+        # dtype / device / contiguity / size of every tensor are checked by the operator itself
+        self._step_op(flags, B, a_geo, a_topo, coin, max_up_in, max_down_in, self.ybuf[self.cur], self.secbuf[self.cur],
+                      self.ybuf[nxt], self.secbuf[nxt], obs=out)
         self.cur = nxt
         return out
 
@@ -264,11 +243,10 @@ class BatchedTruss:
         if coin is None:
             coin = self._coin0
         nxt = self.cur ^ 1
-        a = self._args(0, a_geo_sets, a_topo_sets, coin, None, None, self.ybuf[self.cur], self.secbuf[self.cur],
-                       self.ybuf[nxt], self.secbuf[nxt], want_energy=False)
         with self._on_device():
-            self.lib.check(self.lib.dll.truss_rollout(self.h, C.byref(a), int(n_steps), int(S), self._stream()),
-                           "truss_rollout")
+            ops.call(self._ops.rollout, self._lib_id, self.h.value, ops.stream_of(self.device), 0, self.B, self.N, self.E, int(n_steps), int(S),
+                              *self._step_tensors(a_geo_sets, a_topo_sets, coin, None, None, self.ybuf[self.cur],
+                                                  self.secbuf[self.cur], self.ybuf[nxt], self.secbuf[nxt], False, None))
         if n_steps & 1:
             self.cur = nxt
 
@@ -278,34 +256,13 @@ class BatchedTruss:
         (device tensors).  A_n, mask and nC_e are topology-static: TrussTopology.normalized_adjacency()
         / .incidence()."""
         nact = self._n(n_active)
-        key0 = None if out is None else tuple(0 if out.get(k) is None else out[k].data_ptr() for k in self.OBS_KEYS)
-        if out is None or (self.cur, id(out), nact) + key0 not in self._obs_cache:
-            out = self._obs_out(out, nact)
+        out = self._obs_out(out, nact)
         if nact == 0:
             return out
-        key = (self.cur, id(out), nact) + tuple(0 if out.get(k) is None else out[k].data_ptr()
-                                                for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e"))
-        a = self._obs_cache.get(key)
-        if a is not None:
-            with self._on_device():
-                rc = self.lib.dll.truss_obs(self.h, C.byref(a), self._stream())
-            if rc:
-                self.lib.check(rc, "truss_obs")
-            return out
-        a = _lib.ObsArgs()
-        a.struct_size = C.sizeof(_lib.ObsArgs)
-        a.n_envs, a.flags = nact, 0
-        a.x, a.y, a.sec = _ptr(self.x), _ptr(self.y), _ptr(self.sec)
-        a.max_up, a.max_down, a.target = _ptr(self.max_up), _ptr(self.max_down), _ptr(self.target)
-        a.disp, a.q0, a.sr, a.comp = _ptr(self.disp), _ptr(self.q0), _ptr(self.sr), _ptr(self.comp)
-        a.env_params = _ptr(self.env_params)
-        a.x_n, a.A_s, a.A_n_ts, a.A_n_cs = _ptr(out.get("x_n")), _ptr(out.get("A_s")), _ptr(out.get("A_n_ts")), _ptr(out.get("A_n_cs"))
-        a.nN_x_n, a.nN_x_e = _ptr(out.get("nN_x_n")), _ptr(out.get("nN_x_e"))
-        if len(self._obs_cache) > 16:
-            self._obs_cache.clear()
-        self._obs_cache[key] = a
         with self._on_device():
-            self.lib.check(self.lib.dll.truss_obs(self.h, C.byref(a), self._stream()), "truss_obs")
+            ops.call(self._ops.obs, self._lib_id, self.h.value, ops.stream_of(self.device), nact, self.N, self.E, self.x, self.y, self.sec,
+                          self.max_up, self.max_down, self.target, self.disp, self.q0, self.sr, self.comp, self.env_params,
+                          out.get("x_n"), out.get("A_s"), out.get("A_n_ts"), out.get("A_n_cs"), out.get("nN_x_n"), out.get("nN_x_e"))
         return out
 
     def results(self):

@@ -63,19 +63,16 @@ def pareto_graph(pts, n, index, max_front):
 def gcn_aggregate(lib, adj, h, bias, act):
     """act(adj @ h + bias) through the fused HIP kernel `truss_gcn_aggregate` (inference only, float32).
     adj [N,N] (shared) or [B,N,N]; h [B,N,C] contiguous; act in {None,'relu','sigmoid'}."""
-    import ctypes as C
     B, N, Cc = h.shape
     if N > 64:     # large graphs: a 256 x 256 x C batched GEMM is what rocBLAS is good at; the fused kernel is for the small ones
         out = torch.matmul(adj, h) + bias
         return torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
+    from . import ops
     adj = adj.contiguous()
-    stride = 0 if adj.dim() == 2 or adj.shape[0] == 1 else N * N
+    if adj.dim() == 3 and adj.shape[0] == 1:
+        adj = adj[0]
     out = torch.empty_like(h)
-    stream = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream) if h.is_cuda else None
-    code = {None: 0, "relu": 1, "sigmoid": 2}[act]
-    lib.check(lib.dll.truss_gcn_aggregate(C.c_void_p(adj.data_ptr()), stride, C.c_void_p(h.data_ptr()),
-                                          C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, N, Cc, code, stream),
-              "truss_gcn_aggregate")
+    ops.call(ops.namespace().gcn_aggregate, ops.bind(lib), ops.stream_of(h.device), adj, h, bias, out, {None: 0, "relu": 1, "sigmoid": 2}[act])
     return out
 
 

@@ -38,19 +38,12 @@ def front_hv(points, n_points, ref_points=None, max_front=0, lib=None, stream=No
     out = dict(front_idx=torch.empty((B, P), dtype=torch.int32, device=dev), n_front=torch.empty((B,), dtype=torch.int32, device=dev),
                hv_front=torch.empty((B,), dtype=torch.float64, device=dev), hv_all=torch.empty((B,), dtype=torch.float64, device=dev),
                metrics=torch.empty((B, 5), dtype=torch.float64, device=dev))
-    a = _lib.FrontArgs()
-    a.struct_size = C.sizeof(_lib.FrontArgs)
-    a.n_envs, a.max_points, a.max_front = B, P, int(max_front)
-    a.flags = _lib.F_FRONT_TRUNCATE if max_front else 0
-    a.points, a.n_points = _ptr(points), _ptr(n_points)
     if ref_points is not None:
         assert ref_points.dtype == torch.float64 and ref_points.shape == (B, 2) and ref_points.is_contiguous()
-    a.ref_points = _ptr(ref_points)
-    a.front_idx, a.n_front = _ptr(out["front_idx"]), _ptr(out["n_front"])
-    a.hv_front, a.hv_all, a.metrics = _ptr(out["hv_front"]), _ptr(out["hv_all"]), _ptr(out["metrics"])
-    if stream is None and dev.type == "cuda":
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    lib.check(lib.dll.truss_front(C.byref(a), stream), "truss_front")
+    from . import ops
+    ns, stream_i = ops.namespace(), (ops.stream_of(dev) if stream is None else int(getattr(stream, "value", stream) or 0))
+    ops.call(ns.front, ops.bind(lib), stream_i, int(max_front), _lib.F_FRONT_TRUNCATE if max_front else 0, points, n_points, ref_points,
+             out["front_idx"], out["n_front"], out["hv_front"], out["hv_all"], out["metrics"])
     return out
 
 

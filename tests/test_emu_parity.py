@@ -120,8 +120,12 @@ def test_singular_design_is_flagged(lib):
 def test_argument_errors(lib):
     topo = tm.TrussTopology.grid(6)
     env = tm.BatchedTruss(topo, 4, lib=lib)
-    with pytest.raises(ValueError):
+    with pytest.raises(tm.TrussError, match="a_geo must be Float"):       # dtype / device / contiguity: the operator's checks
         env.step(torch.zeros(4, 12, 2, dtype=torch.float64), torch.zeros(4, 12, 3))
+    with pytest.raises(ValueError):                                          # shapes: the host class
+        env.step(torch.zeros(4, 12, 3), torch.zeros(4, 12, 3))
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(4, 12, 2), torch.zeros(4, 12, 3), obs=dict(x_n=torch.zeros(4, 12, 12)))
     bad = tm.TrussTopology([[0, 1], [1, 2]], np.zeros((3, 2)), np.zeros(3), pair=[1, 0, 2])
     with pytest.raises(tm.TrussError):
         bad.native(lib)
