@@ -275,6 +275,7 @@ def worker(variant, outdir):
     if variant == "train":
         _threebar(outdir)
         _reward(outdir, codedir_test=os.path.join(REF, "test/00_small_bridge/code"))
+        _reward_ext(outdir, codedir_test=os.path.join(REF, "test/00_small_bridge/code"), ENVM=ENVM)
 
 
 def _threebar(outdir):
@@ -430,6 +431,91 @@ def _reward(outdir, codedir_test):
     out["rb_out"] = np.array(rb_out, dtype=np.float64)
     np.savez_compressed(os.path.join(outdir, "reward.npz"), **out)
     print("wrote reward", file=sys.stderr)
+
+
+def _reward_ext(outdir, codedir_test, ENVM):
+    """reward_ext.npz -- what reward.npz does not reach (round-2 additions):
+      * the TEST copies' utils.simple_cull / simple_cull_final (test/00_small_bridge/code/utils.py:11-403, MAX_FRONT 50,
+        wider edge lists), imported under another module name next to the train copy;
+      * fronts LONGER than MAX_FRONT: the reference truncates with random.sample (train utils.py:118-123) -- recorded
+        under a fixed random.seed, which a port that consumes the Python RNG the same way reproduces row for row;
+      * truss2D_ENV.pareto_state_data(pf, index) (train copy :19-38) for 1..20 archive members, every index, and the
+        zero-padded [MAX_PARETO_SIZE] blocks of master_DDPG_truss2D_MO.py:475-593 (np.block, restated here: the master
+        needs tensorflow and cannot be imported)."""
+    import contextlib
+    import importlib.util
+    import io
+    import random
+    import numpy as np
+    import utils as U                                   # train copy (cwd / sys.path[0] = train/code)
+    spec = importlib.util.spec_from_file_location("utils_testcopy", os.path.join(codedir_test, "utils.py"))
+    UT = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):     # the file runs a demo at import (utils.py:533-568)
+        spec.loader.exec_module(UT)
+    rng = np.random.default_rng(2024)
+    out = {"meta": _meta()}
+
+    def cases(n_cases, n_lo, n_hi, convex):
+        res = []
+        for t in range(n_cases):
+            n = int(rng.integers(n_lo, n_hi))
+            if convex:      # many mutually non-dominated rows: a noisy convex curve obj2 ~ (1 - sqrt(obj1))^2
+                a = np.sort(rng.random(n)) * 0.9 + 0.05
+                P = np.stack([a, (1 - np.sqrt(a)) ** 2 + rng.random(n) * 0.002, rng.random(n) * 0.9, rng.random(n) * 0.9], axis=1)
+                P = P[rng.permutation(n)]
+            else:
+                P = rng.random((n, 4))
+                P[:, 2:] *= 1.15
+                if t % 4 == 0:
+                    P = np.round(P, 1)
+                if ((P[:, 2] <= 1) & (P[:, 3] <= 1)).sum() == 0:
+                    P[0, 2:] = 0.5
+            res.append(np.hstack([P, np.arange(n, dtype=np.float64)[:, None]]))
+        return res
+
+    def record(tag, fn, rows_list, seed, width):
+        ins, fronts, scal = [], [], []
+        for rows in rows_list:
+            random.seed(seed)
+            front, max_d, dis_d, p_cd, sum_d, std_cd = fn([list(r) for r in rows.tolist()])
+            pad = np.full((width, 5), np.nan); pad[:len(rows)] = rows
+            f = np.array([list(r[:6]) + [np.nan] * (6 - len(r[:6])) for r in front], dtype=np.float64)   # [obj1, obj2, c1, c2, id, (distance)]
+            fpad = np.full((width, 6), np.nan); fpad[:len(f)] = f
+            ins.append(pad); fronts.append(fpad)
+            scal.append([len(front), max_d, dis_d, p_cd, sum_d, float(std_cd)])
+        out[tag + "_in"] = np.array(ins); out[tag + "_front"] = np.array(fronts)
+        out[tag + "_scalars"] = np.array(scal, dtype=np.float64)
+        out[tag + "_seed"] = np.int64(seed)
+
+    record("testcull", UT.simple_cull, cases(120, 1, 30, False), 5, 32)                 # test copy, n <= MAX_FRONT 50
+    record("testfinal", UT.simple_cull_final, cases(120, 1, 30, False), 5, 32)          # test copy, no truncation
+    record("testfinal_long", UT.simple_cull_final, cases(12, 55, 64, True), 5, 64)      # ... with fronts beyond 50
+    record("trainlong", U.simple_cull, cases(40, 24, 64, True), 3, 64)                   # train copy, fronts beyond MAX_FRONT 20
+    record("testlong", UT.simple_cull, cases(20, 55, 64, True), 3, 64)                   # test copy, fronts beyond MAX_FRONT 50
+
+    # pareto_state_data + padding
+    MAXP = 20                                             # MAX_PARETO_SIZE, master…:475
+    assert ENVM.MAX_FRONT == 20
+    xs, As, meta_n = [], [], []
+    for n in range(1, 21):
+        a = np.sort(rng.random(n)) * 0.9 + 0.05
+        pf = [[float(x), float((1 - np.sqrt(x)) ** 2), 0, 0] for x in a]
+        for index in range(n):
+            x_pf, A_pf = ENVM.pareto_state_data(pf, index=index)
+            add = MAXP - x_pf.shape[0]
+            if add > 0:                                   # master…:488-500 (np.block)
+                x_pad = np.block([[x_pf], [np.zeros((add, 4))]])
+                A_pad = np.block([[A_pf, np.zeros((x_pf.shape[0], add))], [np.zeros((add, x_pf.shape[0])), np.zeros((add, add))]])
+            else:
+                x_pad, A_pad = x_pf[:MAXP, :], A_pf[:MAXP, :MAXP]
+            rec = np.full((MAXP, 2), np.nan); rec[:n] = np.array(pf)[:, :2]
+            xs.append(x_pad); As.append(A_pad); meta_n.append(np.concatenate([[n, index], rec.ravel()]))
+    out["pg_in"] = np.array(meta_n, dtype=np.float64)     # [n, index, obj pairs ...]
+    out["pg_x"] = np.array(xs, dtype=np.float64)
+    out["pg_A"] = np.array(As, dtype=np.float64)
+    out["pg_x_dtype"] = str(ENVM.pareto_state_data([[0.5, 0.5, 0, 0]])[0].dtype)
+    np.savez_compressed(os.path.join(outdir, "reward_ext.npz"), **out)
+    print("wrote reward_ext", file=sys.stderr)
 
 
 def main():
