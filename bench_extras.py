@@ -74,4 +74,43 @@ def run(tm, synthetic, lib, dev, topo, env, G, T, args, B):
         extras[f"large_{tb.N}n_{tb.E}e_{b_big}envs"] = {"us_per_step": us, "env_steps_per_s": b_big / (us * 1e-6),
                                                            "lanes_per_env": tb.solver_info(lib)["lanes_per_env"],
                                                            "nonpositive_pivots": int(eb.status.sum().item())}
+    # BASELINE configs[4]: the mixed 32-256-node pool on one GPU (one BatchedTruss per size class, one stream per class)
+    from truss_mi355 import pool
+    import time
+    classes = pool.grid_classes([16, 32, 64, 128], [2048, 1024, 512, 256])
+    for tag, streams in (("mixed_pool_32_64_128_256_nodes", True), ("mixed_pool_same_one_stream", False)):
+        p = pool.MixedTrussPool(classes, bucket_envs=64, device=dev, lib=lib, streams=streams)
+        batches, acts = [], []
+        for k, e in enumerate(p.envs):
+            b = synthetic.random_batch(e.topo, e.B, seed=30 + k)
+            batches.append(b)
+            ag, at = synthetic.random_actions(1, e.B, e.N, 60 + k)
+            acts.append((torch.tensor(ag[0], device=dev), torch.tensor(at[0], device=dev)))
+        p.set_constants(batches); p.set_design(batches); p.analyze(set_normalisers=True)
+        for _ in range(5):
+            p.step(acts)
+        torch.cuda.synchronize()
+        a0.record()
+        for _ in range(50):
+            p.step(acts)
+        a1.record(); torch.cuda.synchronize()
+        us = a0.elapsed_time(a1) * 1e3 / 50
+        extras[tag] = {"envs": p.sizes, "us_per_pool_step": us, "env_steps_per_s": p.n_envs / (us * 1e-6), "nonpositive_pivots": int(p.status.sum().item())}
+        for _ in range(5):
+            p.step(acts, obs=True)
+        torch.cuda.synchronize()
+        a0.record()
+        for _ in range(30):
+            p.step(acts, obs=True)
+        a1.record(); torch.cuda.synchronize()
+        extras[tag]["us_per_pool_step_with_obs"] = a0.elapsed_time(a1) * 1e3 / 30
+        del p
+    # BASELINE configs[2]: small_roof, 4096 envs, MADDPG GCN agents in the loop (tools/marl_bench.py)
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import marl_bench
+    for tag, train in (("marl_small_roof_4096", True), ("marl_small_roof_4096_no_training", False)):
+        r = marl_bench.run(4096, 4, train, 8)
+        extras[tag] = {k: r[k] for k in ("env_steps_per_s", "env_steps", "seconds", "mean_front", "game_steps")}
     return extras

@@ -203,9 +203,11 @@ class BatchedMARL:
         self.game_step = 1
 
     # ---- observation tensors in the networks' order ----
-    def _obs(self, env, pts0, n0, index, rep=1, k=None):
+    def _obs(self, env, pts0, n0, index, rep=1, k=None, o=None):
+        """o: observation tensors the analysis / step call has already written (TRUSS_F_EMIT_OBS); None = observation kernel"""
         k = env.B if k is None else k
-        o = env.observe(n_active=k)
+        if o is None:
+            o = env.observe(n_active=k)
         x_p, A_p = pareto_graph(pts0, n0, index, self.P)
         if rep > 1:
             x_p, A_p = x_p.repeat(rep, 1, 1), A_p.repeat(rep, 1, 1)
@@ -302,7 +304,9 @@ class BatchedMARL:
         g.replay()
 
     # ---- one game step of every env (run() :198-705) ----
-    def game_step_all(self, train: bool = True, explore: bool = True, train_iters: int = 1):
+    def game_step_all(self, train: bool = True, explore: bool = True, train_iters: int = 1, update: bool = True):
+        """train: push accepted transitions to the replay and (with `update`) run `train_iters` MADDPG updates from it;
+        update=False leaves the updates to the caller (MixedMARL: one set of agents over several size classes)."""
         B, P = self.B, self.P
         pts0, n0 = self.pts.clone(), self.n.clone()                   # front_no / Pf_HV of this step (:203-209)
         y0, sec0 = self.arch_y.clone(), self.arch_sec.clone()
@@ -326,8 +330,7 @@ class BatchedMARL:
             eP, eC = self.envP, self.envC
             eP.x[:K], eP.target[:K], eP.env_params[:K] = cx, ct, cp
             eP.y[:K], eP.sec[:K] = py, ps
-            eP.analyze(n_active=K)
-            S = self._obs(eP, p0, nn0, idx_m, k=K)
+            S = self._obs(eP, p0, nn0, idx_m, k=K, o=eP.analyze(n_active=K, obs=True))   # analysis + observations: one launch
             tk = self._tick("parent analysis + obs", tk)
             geo, topo = self._act(S, explore)
             tk = self._tick("actors", tk)
@@ -335,9 +338,9 @@ class BatchedMARL:
             eC.x[:3 * K], eC.target[:3 * K], eC.env_params[:3 * K] = cx.repeat(3, 1), ct.repeat(3, 1), cp.repeat(3, 1)
             eC.y[:3 * K], eC.sec[:3 * K] = py.repeat(3, 1), ps.repeat(3, 1)
             a_geo, a_topo = torch.cat(geo, 0).contiguous(), torch.cat(topo, 0).contiguous()
-            eC.step(a_geo, a_topo, clamp_inplace=True, n_active=3 * K)   # clamped actions go to the replay (:375)
-            self._steps_dev += 3 * K
-            NSall = self._obs(eC, p0, nn0, idx_m, rep=3, k=3 * K)
+            oC = eC.step(a_geo, a_topo, clamp_inplace=True, n_active=3 * K, obs=True)   # clamped actions go to the replay (:375);
+            self._steps_dev += 3 * K                                                     # step + next-state observations: one launch
+            NSall = self._obs(eC, p0, nn0, idx_m, rep=3, k=3 * K, o=oC)
             tk = self._tick("candidate step + obs", tk)
             points = eC.point[:3 * K].view(3, K, 4).permute(1, 0, 2).double().contiguous()
             cand_y = eC.y[:3 * K].view(3, K, -1).permute(1, 0, 2)
@@ -386,6 +389,16 @@ class BatchedMARL:
         hv = RW.front_hv(self.pts.contiguous(), self.n, None, 0, self.lib)
         self.ref_points = torch.clamp(self.ref_points + self.hv_margin, max=1.0)
         self.game_step += 1
+        if update:
+            self.train_from_replay(train_iters if train else 0)
+        tk = self._tick("train", tk)
+        return dict(hv=hv["hv_front"], n_front=self.n.clone(), sum_distance=hv["metrics"][:, 3], reward=rsum, replay_added=added,
+                    replay_size=self.replay.size)
+
+    def train_from_replay(self, train_iters: int = 1):
+        """`train_iters` MADDPG updates on batches sampled from this engine's replay (when it holds a batch; collective
+        decision under data parallelism).  Returns the number of updates run."""
+        train = train_iters > 0
         ready = train and self.replay.size >= self.batch_size
         d = getattr(self.rl, "dist", None)
         if train and d is not None and d.is_initialized() and d.get_world_size() > 1:
@@ -407,6 +420,54 @@ class BatchedMARL:
                 S, NS, ag, at, R = self.replay.sample(self.batch_size, self.gen)
                 A = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
                 self._train(self._net_state(S), [self._net_state(ns) for ns in NS], A, R)
-        tk = self._tick("train", tk)
-        return dict(hv=hv["hv_front"], n_front=self.n.clone(), sum_distance=hv["metrics"][:, 3], reward=rsum, replay_added=added,
-                    replay_size=self.replay.size)
+            return train_iters
+        return 0
+
+
+class MixedMARL:
+    """The batched rollout over a MIX of truss sizes with ONE set of agents (BASELINE configs[4]; the reference trains one
+    MADDPG on a different truss every episode, master…:807-825; its GCN layers do not depend on the node count).
+
+    One `BatchedMARL` engine per size class -- archives, env objects and replay have the class's shapes -- all sharing
+    `maddpg`.  Envs are dealt to ranks in buckets like `MixedTrussPool` (pool.deal_buckets): every rank plays the same
+    class mix.  A game step plays every class; the updates of the step then draw their batches from the classes'
+    replays in turn (a batch is of one class: its tensors have that class's shapes)."""
+
+    def __init__(self, classes, maddpg, *, bucket_envs=64, rank=0, world=1, **engine_kw):
+        from .pool import deal_buckets
+        self.classes = [(t, int(n)) for t, n in classes]
+        self.share = deal_buckets([n for _, n in self.classes], bucket_envs, world)
+        self.class_ids, self.ranges, self.engines = [], [], []
+        for c, (topo, _) in enumerate(self.classes):
+            n_local = sum(hi - lo for lo, hi in self.share[rank][c])
+            if n_local:
+                self.class_ids.append(c)
+                self.ranges.append(self.share[rank][c])
+                self.engines.append(BatchedMARL(topo, n_local, maddpg, **engine_kw))
+        self.rl = maddpg
+        self._turn = 0
+
+    def global_ids(self, k):
+        return np.concatenate([np.arange(lo, hi) for lo, hi in self.ranges[k]])
+
+    @property
+    def env_steps(self):
+        return sum(e.env_steps for e in self.engines)
+
+    def reset(self, per_class):
+        """per_class[k]: dict(x, target, y_max, d_min, max_def, load_x, load_y, is_roof, y, sec) of this rank's k-th class"""
+        for e, b in zip(self.engines, per_class):
+            e.reset(b["x"], b["target"], b["y_max"], b["d_min"], b["max_def"], b["load_x"], b["load_y"], b["is_roof"], b["y"], b["sec"])
+
+    def game_step_all(self, train: bool = True, explore: bool = True, train_iters: int = 1):
+        outs = [e.game_step_all(train=train, explore=explore, update=False) for e in self.engines]
+        done = 0
+        if train:
+            for _ in range(train_iters):                       # one class per update, in turn
+                for _try in range(len(self.engines)):
+                    e = self.engines[self._turn % len(self.engines)]
+                    self._turn += 1
+                    if e.train_from_replay(1):
+                        done += 1
+                        break
+        return dict(per_class=outs, updates=done, hv=torch.cat([o["hv"] for o in outs]), n_front=torch.cat([o["n_front"] for o in outs]))

@@ -150,3 +150,56 @@ def test_shard_bounds_cover_the_batch():
         b = [distributed.shard_bounds(ge, world, r) for r in range(world)]
         assert b[0][0] == 0 and b[-1][1] == ge and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
         assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def _pool_setup(lib, rank, world):
+    """a rank's share of a 3-class pool, stepped once with the class's global actions restricted to the rank's envs"""
+    from truss_mi355 import pool, synthetic
+    classes = pool.grid_classes([4, 6, 8], [12, 8, 4])
+    p = pool.MixedTrussPool(classes, bucket_envs=2, rank=rank, world=world, lib=lib)
+    batches, acts = [], []
+    for k, e in enumerate(p.envs):
+        c, ids = p.class_ids[k], p.global_ids(k)
+        full = synthetic.random_batch(e.topo, classes[c][1], 40 + c)
+        batches.append({key: v[ids] for key, v in full.items()})
+        ag, at = synthetic.random_actions(1, classes[c][1], e.N, 50 + c)
+        acts.append((torch.tensor(ag[0][ids]), torch.tensor(at[0][ids])))
+    p.set_constants(batches)
+    p.set_design(batches)
+    p.analyze(set_normalisers=True)
+    p.step(acts)
+    return p
+
+
+def _pool_worker(rank, world, port, lib_path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import truss_mi355 as tm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = _pool_setup(tm.load(lib_path), rank, world)
+    mix = torch.tensor([p.sizes[p.class_ids.index(c)] if c in p.class_ids else 0 for c in range(3)], dtype=torch.int64)
+    mixes = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(mixes, mix)
+    s = p.point.double().sum(dim=0)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)                 # metrics only: no env data crosses ranks
+    if rank == 0:
+        out.put(([m.tolist() for m in mixes], s.tolist(), p.class_mix().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mixed_pool_has_the_same_class_mix_on_every_rank():
+    lib_path = pc.build_emu()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pool_worker, args=(r, 2, port, lib_path, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mixes, total, planned = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert mixes == planned == [[6, 4, 2], [6, 4, 2]]        # round-robin buckets: every rank plays 6 + 4 + 2 envs of the 3 classes
+    import truss_mi355 as tm
+    whole = _pool_setup(tm.load(lib_path), 0, 1)              # the same envs in one process
+    np.testing.assert_allclose(total, whole.point.double().sum(dim=0).tolist(), rtol=1e-12)

@@ -20,12 +20,9 @@ import master_DDPG_truss2D_MO as M
 import truss2D_RL as RL
 
 
-def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-    train = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
-    nx = int(sys.argv[4]) if len(sys.argv) > 4 else 8     # bays + 1; 8 = test/01_small_roof (16 nodes, 36 elements);
-    dev = "cuda"                                          # 16 / 32 / 64 / 128 = the size classes of BASELINE configs[4]
+def run(B=4096, steps=6, train=True, nx=8, profile=False):
+    """nx = bays + 1; 8 = test/01_small_roof (16 nodes, 36 elements); 16 / 32 / 64 / 128 = the size classes of BASELINE configs[4]"""
+    dev = "cuda"
     topo = tm.TrussTopology.grid(nx)
     rl = RL.MADDPG(M.lr, M.ep, M.epd, M.gamma, M.a_nn, M.c_nn, 100, M.num_agents, M.num_action, M.mu, M.theta, M.sigma, device=dev)
     eng = marl.BatchedMARL(topo, B, rl, max_front=20, device=dev, replay_capacity=32768, batch_size=32)
@@ -38,7 +35,7 @@ def main():
         eng.game_step_all(train=train)                    # warm-up (lazy layers, first launches)
     torch.cuda.synchronize()
     e0 = eng.env_steps
-    if os.environ.get("MARL_PROFILE"):
+    if profile:
         eng.profile = {}
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
@@ -46,10 +43,18 @@ def main():
             st = eng.game_step_all(train=train)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"config": f"roof truss {topo.N}n/{topo.E}e, MADDPG GCN agents in the loop", "envs": B, "game_steps": steps, "train": train,
-                      "env_steps": eng.env_steps - e0, "seconds": dt, "env_steps_per_s": (eng.env_steps - e0) / dt,
-                      "mean_front": float(st["n_front"].float().mean()), "mean_hv": float(st["hv"].mean()),
-                      "replay_size": st["replay_size"], "profile_s": eng.profile}))
+    return {"config": f"roof truss {topo.N}n/{topo.E}e, MADDPG GCN agents in the loop", "envs": B, "game_steps": steps, "train": train,
+            "env_steps": eng.env_steps - e0, "seconds": dt, "env_steps_per_s": (eng.env_steps - e0) / dt,
+            "mean_front": float(st["n_front"].float().mean()), "mean_hv": float(st["hv"].mean()),
+            "replay_size": st["replay_size"], "profile_s": eng.profile}
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    train = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
+    nx = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+    print(json.dumps(run(B, steps, train, nx, bool(os.environ.get("MARL_PROFILE")))))
 
 
 if __name__ == "__main__":
