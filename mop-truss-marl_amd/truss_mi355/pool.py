@@ -9,8 +9,10 @@ round-robin buckets across GPUs so each rank gets the same class mix":
     round-robin over the ranks -- every rank ends up with (almost) the same number of envs of every class, so no rank is
     left with only the expensive 256-node trusses;
   * on a rank, the buckets of one class are merged into one `BatchedTruss` (one launch per class and step);
-  * classes are independent: each class's launches go to its own HIP stream, so the small launches of different
-    classes overlap on the chip (a 256-node class at a few hundred envs fills a fraction of the CUs);
+  * classes are independent; `streams=True` puts each class's launches on its own HIP stream.  Measured on one MI355X
+    (2048 / 1024 / 512 / 256 envs of 32 / 64 / 128 / 256 nodes): 190 us per pool step with streams against 163 us on one
+    stream (the launches do not overlap enough to pay for the event hand-shakes), 348 against 365 us with the observation
+    tensors -- hence off by default;
   * `step / analyze / observe` fan out over the classes; `point`, `status`, `obj` come back concatenated in POOL ORDER
     (class-major, bucket order), with `index()` mapping pool rows back to (class, local env).
 
@@ -42,7 +44,7 @@ class MixedTrussPool:
     """classes: list of (TrussTopology, n_envs_global).  rank / world: this process's place in the job (one process
     per GPU).  The pool owns one BatchedTruss per class with envs on this rank."""
 
-    def __init__(self, classes, *, bucket_envs=64, rank=0, world=1, device=None, lib=None, streams=True):
+    def __init__(self, classes, *, bucket_envs=64, rank=0, world=1, device=None, lib=None, streams=False):
         self.classes = [(t, int(n)) for t, n in classes]
         self.rank, self.world, self.bucket_envs = int(rank), int(world), int(bucket_envs)
         self.share = deal_buckets([n for _, n in self.classes], bucket_envs, world)
