@@ -301,15 +301,17 @@ class MADDPG:
         orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]          # (self, other1, other2) per agent (:561-563)
         self._ensure_ready(S, flat(orders[0]))
         with torch.no_grad():
-            q_next = []
-            for f in range(3):
-                na = [ag.target_actor_model(self._actor_in(NS[f])) for ag in self.agents]
-                qf = []
-                for i, ag in enumerate(self.agents):
-                    o = orders[i]
-                    qf.append(ag.target_critic_model(NS[f] + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1],
-                                                              na[o[2]][0], na[o[2]][1]]))
-                q_next.append(qf)
+            # the three next states (one per agent's move, :561-600) go through the target networks as ONE batch of
+            # 3 x batch samples: 6 network passes instead of 18 (the update is bound by its kernel count)
+            nb = NS[0][0].shape[0]
+            NSc = [torch.cat([NS[f][k] for f in range(3)], dim=0) for k in range(len(NS[0]))]
+            na = [ag.target_actor_model(self._actor_in(NSc)) for ag in self.agents]
+            q_next = [[None] * 3 for _ in range(3)]
+            for i, ag in enumerate(self.agents):
+                o = orders[i]
+                q = ag.target_critic_model(NSc + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1], na[o[2]][0], na[o[2]][1]])
+                for f in range(3):
+                    q_next[f][i] = q[f * nb:(f + 1) * nb]
         for i, ag in enumerate(self.agents):
             o = orders[i]
             # TD target; `done` never fires in the reference (it compares an action array with `is 1`)

@@ -11,13 +11,18 @@ once, every piece on the device:
     archive update                    reward.front_hv + gathers
     replay + MADDPG update            device tensors, MADDPG.train_on_batch
 
+One game step is ONE flat pass over all live (env, archive member) pairs (member-major list, in chunks of at most
+`pair_capacity` pairs): one parent analysis, one actor pass per agent, one candidate launch, one reward evaluation for
+all of them -- not one pass per member index, whose later, thin iterations were bound by launch overhead.
+
 Differences from the per-env loop, all forced by batching and documented here:
-  D1  the archive is culled after every archive member's three candidates instead of once per game step
-      (the Pareto front of a union is the front of the partial fronts, so the resulting set is the same
-      unless the MAX_FRONT truncation intervenes); rewards still use the front at the START of the game
-      step, like the reference (front_no / Pf_HV, :263-368);
-  D2  a transition enters the replay when its candidate is accepted into the archive at insertion time
-      (the reference remembers the candidates that survive the end-of-step cull, :595-621);
+  D1  the archive is culled once per chunk of pairs -- for an archive of up to 14 members (MAX_FRONT 20: the front
+      kernel takes 64 rows = 20 archive rows + the 3 x 14 candidates of 14 members) that is once per game step, like the
+      reference (:430); larger archives are folded in two rounds (the Pareto front of a union is the front of the
+      partial fronts, so the set is the same unless the MAX_FRONT truncation intervenes); rewards use the front at
+      the START of the game step, like the reference (front_no / Pf_HV, :263-368);
+  D2  a transition enters the replay when its candidate is in the archive after that cull (the reference remembers the
+      candidates that survive the end-of-step cull, :595-621);
   D3  truncation to MAX_FRONT is deterministic (largest crowding distance), see include/truss_mi355.h;
   D4  when an agent's move is infeasible its next state in the replay is the first feasible agent's
       (the reference draws a random survivor, :380-407); the Pareto-graph inputs (x_p, A_p) of the next
@@ -139,11 +144,17 @@ class DeviceReplay:
 
 class BatchedMARL:
     def __init__(self, topo: TrussTopology, n_envs: int, maddpg, *, max_front: int = 20, lib=None, device=None,
-                 replay_capacity: int = 32768, batch_size: int = 32, hv_margin: float = 0.2, seed: int = 0):
+                 replay_capacity: int = 32768, batch_size: int = 32, hv_margin: float = 0.2, seed: int = 0,
+                 pair_capacity: int | None = None):
         self.topo, self.B, self.P = topo, int(n_envs), int(max_front)
         self.rl = maddpg
-        self.envP = BatchedTruss(topo, self.B, device=device, lib=lib)          # archive members under study
-        self.envC = BatchedTruss(topo, 3 * self.B, device=device, lib=lib)      # their candidates, agent-major
+        # members whose candidates fit one cull: P archive rows + 3 candidates per member <= the front kernel's 64 rows
+        self.Gm = max(1, min(self.P, (64 - self.P) // 3))
+        # (env, member) pairs per pass: the env objects below hold that many designs (3 x as many candidates)
+        self.cap = int(pair_capacity) if pair_capacity else min(self.B * self.Gm, 4 * self.B)
+        self.cap = max(self.cap, self.B)
+        self.envP = BatchedTruss(topo, self.cap, device=device, lib=lib)          # archive members under study
+        self.envC = BatchedTruss(topo, 3 * self.cap, device=device, lib=lib)      # their candidates, agent-major
         self.lib, self.device = self.envP.lib, self.envP.device
         dev, B, P, N, E = self.device, self.B, self.P, topo.N, topo.E
         A_n, mask = topo.normalized_adjacency()
@@ -186,18 +197,19 @@ class BatchedMARL:
                 return a
             a = np.broadcast_to(a, (self.B,) + a.shape[1:]) if a.shape[0] != self.B else a
             return np.tile(a, (rep,) + (1,) * (a.ndim - 1))
-        for env, rep in ((self.envP, 1), (self.envC, 3)):
-            env.set_constants(*[tiled(a, rep) for a in (x, target, y_max, d_min, max_def, load_x, load_y, is_roof)])
-        self.envP.set_design(y0, sec0)
-        self.envP.analyze(set_normalisers=True)
-        self.envC.env_params.copy_(self.envP.env_params.repeat(3, 1))
-        # per-env constants of the whole batch: the env objects are re-filled with the LIVE envs of every member
-        # iteration, compacted to the front (BatchedTruss n_active)
-        self.c_x, self.c_target, self.c_params = self.envP.x.clone(), self.envP.target.clone(), self.envP.env_params.clone()
+        # the reset analysis of the B designs (normalisers int_obj1 / int_obj2, :264-274) on a B-env object
+        e0 = BatchedTruss(self.topo, self.B, device=self.device, lib=self.lib)
+        e0.set_constants(*[tiled(a, 1) for a in (x, target, y_max, d_min, max_def, load_x, load_y, is_roof)])
+        e0.set_design(y0, sec0)
+        e0.analyze(set_normalisers=True)
+        # per-env constants of the whole batch: the pair-sized env objects are re-filled with the constants of the LIVE
+        # (env, member) pairs of every pass, compacted to the front (BatchedTruss n_active)
+        self.c_x, self.c_target, self.c_params = e0.x.clone(), e0.target.clone(), e0.env_params.clone()
+        self._y_reset, self._sec_reset = e0.y.clone(), e0.sec.clone()
         self.pts.zero_(); self.arch_y.zero_(); self.arch_sec.zero_()
         self.pts[:, 0, 0:2] = 1.0                                    # Pf = [[1, 1, 0, 0, S0, ...]] (:168)
-        self.arch_y[:, 0] = self.envP.y
-        self.arch_sec[:, 0] = self.envP.sec
+        self.arch_y[:, 0] = self._y_reset
+        self.arch_sec[:, 0] = self._sec_reset
         self.n.fill_(1)
         self.ref_points.fill_(1.0)
         self.game_step = 1
@@ -307,84 +319,99 @@ class BatchedMARL:
     def game_step_all(self, train: bool = True, explore: bool = True, train_iters: int = 1, update: bool = True):
         """train: push accepted transitions to the replay and (with `update`) run `train_iters` MADDPG updates from it;
         update=False leaves the updates to the caller (MixedMARL: one set of agents over several size classes)."""
-        B, P = self.B, self.P
+        B, P, Gm = self.B, self.P, self.Gm
         pts0, n0 = self.pts.clone(), self.n.clone()                   # front_no / Pf_HV of this step (:203-209)
         y0, sec0 = self.arch_y.clone(), self.arch_sec.clone()
         added = 0
         rsum = torch.zeros((B, 3), dtype=torch.float64, device=self.device)
         tk = time.perf_counter()
         dev = self.device
-        for m in range(int(n0.max().item())):
-            tk = self._tick("other", tk)
-            # live envs of this member index, compacted to the front of the env objects: the work of an
-            # iteration is proportional to the number of envs whose archive has a member m
-            idx = torch.nonzero(n0 > m, as_tuple=False).flatten()
-            K = int(idx.numel())
-            if K == 0:
-                break
-            p0, nn0 = pts0[idx].contiguous(), n0[idx].contiguous()
-            idx_m = torch.full((K,), m, dtype=torch.int64, device=dev)
-            py, ps = y0[idx, m], sec0[idx, m]
-            cx, ct, cp = self.c_x[idx], self.c_target[idx], self.c_params[idx]
-            # parents: member m of the step-start archive (:211-221)
-            eP, eC = self.envP, self.envC
-            eP.x[:K], eP.target[:K], eP.env_params[:K] = cx, ct, cp
-            eP.y[:K], eP.sec[:K] = py, ps
-            S = self._obs(eP, p0, nn0, idx_m, k=K, o=eP.analyze(n_active=K, obs=True))   # analysis + observations: one launch
-            tk = self._tick("parent analysis + obs", tk)
-            geo, topo = self._act(S, explore)
-            tk = self._tick("actors", tk)
-            # the three agents modify the SAME parent (:249-260): one launch over 3 K envs, agent-major
-            eC.x[:3 * K], eC.target[:3 * K], eC.env_params[:3 * K] = cx.repeat(3, 1), ct.repeat(3, 1), cp.repeat(3, 1)
-            eC.y[:3 * K], eC.sec[:3 * K] = py.repeat(3, 1), ps.repeat(3, 1)
-            a_geo, a_topo = torch.cat(geo, 0).contiguous(), torch.cat(topo, 0).contiguous()
-            oC = eC.step(a_geo, a_topo, clamp_inplace=True, n_active=3 * K, obs=True)   # clamped actions go to the replay (:375);
-            self._steps_dev += 3 * K                                                     # step + next-state observations: one launch
-            NSall = self._obs(eC, p0, nn0, idx_m, rep=3, k=3 * K, o=oC)
-            tk = self._tick("candidate step + obs", tk)
-            points = eC.point[:3 * K].view(3, K, 4).permute(1, 0, 2).double().contiguous()
-            cand_y = eC.y[:3 * K].view(3, K, -1).permute(1, 0, 2)
-            cand_sec = eC.sec[:3 * K].view(3, K, -1).permute(1, 0, 2)
-            R, _, _, _ = RW.difference_reward(p0, nn0, p0, nn0, p0[:, m, :2].contiguous(), points, self.ref_points[idx].contiguous(),
-                                              nn0, max_front=P, lib=self.lib)
-            rsum[idx] += R
-            tk = self._tick("reward", tk)
-            ok = (points[:, :, 2] <= 1) & (points[:, :, 3] <= 1)                          # archive candidates (:372)
-            # ---- archive update (D1): front of (working archive + feasible candidates) ----
-            wp, wy, ws, wn = self.pts[idx], self.arch_y[idx], self.arch_sec[idx], self.n[idx]
-            allp = torch.cat([wp, points], dim=1).clone()
-            ar = torch.arange(P, device=dev)
-            dead = torch.cat([ar[None, :] >= wn[:, None], ~ok], dim=1)
-            allp[:, :, 2] = torch.where(dead, torch.full_like(allp[:, :, 2], 2.0), allp[:, :, 2])   # infeasible marker
-            fr = RW.front_hv(allp.contiguous(), torch.full((K,), P + 3, dtype=torch.int32, device=dev), None,
-                             max_front=P, lib=self.lib)
-            fidx = fr["front_idx"][:, :P].long()
-            take = fidx.clamp(min=0)
-            ally = torch.cat([wy, cand_y], dim=1)
-            alls = torch.cat([ws, cand_sec], dim=1)
-            origp = torch.cat([wp, points], dim=1)
-            rows = torch.arange(K, device=dev)[:, None]
-            live = fidx >= 0
-            newp = torch.where(live[:, :, None], origp[rows, take], torch.zeros_like(wp))
-            newp[:, :, 0:2] = torch.minimum(newp[:, :, 0:2], torch.ones_like(newp[:, :, 0:2]))      # :434-436
-            self.pts[idx] = newp
-            self.arch_y[idx] = torch.where(live[:, :, None], ally[rows, take], torch.zeros_like(wy))
-            self.arch_sec[idx] = torch.where(live[:, :, None], alls[rows, take], torch.zeros_like(ws))
-            self.n[idx] = fr["n_front"].clamp(max=P)
-            tk = self._tick("archive update", tk)
-            # ---- replay (D2): one row per accepted candidate ----
-            if train:
-                accepted = torch.stack([(fidx == P + a).any(dim=1) for a in range(3)], dim=1) & ok
-                first_ok = torch.argmax(ok.int(), dim=1)                                   # D4
+        N, E = self.topo.N, self.topo.E
+        arP = torch.arange(P, device=dev)
+        n_max = int(n0.max().item())
+        for g0 in range(0, n_max, Gm):                                # member groups whose candidates fit one cull
+            # live (env, member) pairs of this group, member-major: pair k = (env pb[k], member pm[k])
+            livemask = (arP[None, g0:g0 + Gm] < n0[:, None])          # [B, Gm]
+            pm_all, pb_all = torch.nonzero(livemask.t(), as_tuple=True)
+            pm_all = pm_all + g0
+            for c0 in range(0, int(pb_all.numel()), self.cap):
+                tk = self._tick("other", tk)
+                idx, ms = pb_all[c0:c0 + self.cap], pm_all[c0:c0 + self.cap]
+                K = int(idx.numel())
                 ark = torch.arange(K, device=dev)
-                NS = []
-                for a in range(3):
-                    src = torch.where(ok[:, a], torch.full_like(first_ok, a), first_ok)
-                    NS.append({k: NSall[k].view(3, K, *NSall[k].shape[1:])[src, ark] for k in DeviceReplay.KEYS})
-                ag = a_geo.view(3, K, -1, 2).permute(1, 0, 2, 3)
-                at = a_topo.view(3, K, -1, 3).permute(1, 0, 2, 3)
-                added += self.replay.add(accepted.any(dim=1), S, NS, ag, at, R.float())
-            tk = self._tick("replay", tk)
+                p0, nn0 = pts0[idx].contiguous(), n0[idx].contiguous()
+                py, ps = y0[idx, ms], sec0[idx, ms]
+                cx, ct, cp = self.c_x[idx], self.c_target[idx], self.c_params[idx]
+                # parents: the members of the step-start archive (:211-221)
+                eP, eC = self.envP, self.envC
+                eP.x[:K], eP.target[:K], eP.env_params[:K] = cx, ct, cp
+                eP.y[:K], eP.sec[:K] = py, ps
+                S = self._obs(eP, p0, nn0, ms, k=K, o=eP.analyze(n_active=K, obs=True))   # analysis + observations: one launch
+                tk = self._tick("parent analysis + obs", tk)
+                geo, topo = self._act(S, explore)
+                tk = self._tick("actors", tk)
+                # the three agents modify the SAME parent (:249-260): one launch over 3 K envs, agent-major
+                eC.x[:3 * K], eC.target[:3 * K], eC.env_params[:3 * K] = cx.repeat(3, 1), ct.repeat(3, 1), cp.repeat(3, 1)
+                eC.y[:3 * K], eC.sec[:3 * K] = py.repeat(3, 1), ps.repeat(3, 1)
+                a_geo, a_topo = torch.cat(geo, 0).contiguous(), torch.cat(topo, 0).contiguous()
+                oC = eC.step(a_geo, a_topo, clamp_inplace=True, n_active=3 * K, obs=True)   # clamped actions go to the replay (:375);
+                self._steps_dev += 3 * K                                                     # step + next-state observations: one launch
+                NSall = self._obs(eC, p0, nn0, ms, rep=3, k=3 * K, o=oC)
+                tk = self._tick("candidate step + obs", tk)
+                points = eC.point[:3 * K].view(3, K, 4).permute(1, 0, 2).double().contiguous()
+                cand_y = eC.y[:3 * K].view(3, K, -1).permute(1, 0, 2)
+                cand_sec = eC.sec[:3 * K].view(3, K, -1).permute(1, 0, 2)
+                R, _, _, _ = RW.difference_reward(p0, nn0, p0, nn0, p0[ark, ms, :2].contiguous(), points, self.ref_points[idx].contiguous(),
+                                                  nn0, max_front=P, lib=self.lib)
+                rsum.index_add_(0, idx, R)
+                tk = self._tick("reward", tk)
+                ok = (points[:, :, 2] <= 1) & (points[:, :, 3] <= 1)                          # archive candidates (:372)
+                # ---- archive update (D1): front of (working archive + the feasible candidates of this chunk's members) ----
+                C3 = 3 * Gm
+                slot = ((ms - g0) * 3)[:, None] + torch.arange(3, device=dev)[None, :]        # [K, 3] candidate slot of (pair, agent)
+                candP = torch.zeros((B, C3, 4), dtype=torch.float64, device=dev)
+                candP[:, :, 2] = 2.0                                                          # empty slot = infeasible row
+                candY = torch.zeros((B, C3, N), dtype=torch.float32, device=dev)
+                candS = torch.zeros((B, C3, E), dtype=torch.int32, device=dev)
+                pmark = points.clone()
+                pmark[:, :, 2] = torch.where(ok, pmark[:, :, 2], torch.full_like(pmark[:, :, 2], 2.0))
+                candP[idx[:, None], slot] = pmark
+                candY[idx[:, None], slot] = cand_y
+                candS[idx[:, None], slot] = cand_sec
+                wp, wy, ws, wn = self.pts, self.arch_y, self.arch_sec, self.n
+                allp = torch.cat([wp, candP], dim=1).clone()
+                dead = arP[None, :] >= wn[:, None]
+                allp[:, :P, 2] = torch.where(dead, torch.full_like(allp[:, :P, 2], 2.0), allp[:, :P, 2])   # infeasible marker
+                fr = RW.front_hv(allp.contiguous(), torch.full((B,), P + C3, dtype=torch.int32, device=dev), None,
+                                 max_front=P, lib=self.lib)
+                fidx = fr["front_idx"][:, :P].long()
+                take = fidx.clamp(min=0)
+                ally = torch.cat([wy, candY], dim=1)
+                alls = torch.cat([ws, candS], dim=1)
+                origp = torch.cat([wp, candP], dim=1)
+                rows = torch.arange(B, device=dev)[:, None]
+                live = fidx >= 0
+                newp = torch.where(live[:, :, None], origp[rows, take], torch.zeros_like(wp))
+                newp[:, :, 0:2] = torch.minimum(newp[:, :, 0:2], torch.ones_like(newp[:, :, 0:2]))      # :434-436
+                self.pts = newp
+                self.arch_y = torch.where(live[:, :, None], ally[rows, take], torch.zeros_like(wy))
+                self.arch_sec = torch.where(live[:, :, None], alls[rows, take], torch.zeros_like(ws))
+                self.n = fr["n_front"].clamp(max=P).to(torch.int32)
+                tk = self._tick("archive update", tk)
+                # ---- replay (D2): one row per pair with an accepted candidate ----
+                if train:
+                    infront = torch.zeros((B, P + C3), dtype=torch.bool, device=dev)
+                    infront.scatter_(1, take, live)
+                    accepted = infront[idx[:, None], P + slot] & ok                          # [K, 3]
+                    first_ok = torch.argmax(ok.int(), dim=1)                                   # D4
+                    NS = []
+                    for a in range(3):
+                        src = torch.where(ok[:, a], torch.full_like(first_ok, a), first_ok)
+                        NS.append({k: NSall[k].view(3, K, *NSall[k].shape[1:])[src, ark] for k in DeviceReplay.KEYS})
+                    ag = a_geo.view(3, K, -1, 2).permute(1, 0, 2, 3)
+                    at = a_topo.view(3, K, -1, 3).permute(1, 0, 2, 3)
+                    added += self.replay.add(accepted.any(dim=1), S, NS, ag, at, R.float())
+                tk = self._tick("replay", tk)
         # ---- end of the game step (:430-473, 642) ----
         hv = RW.front_hv(self.pts.contiguous(), self.n, None, 0, self.lib)
         self.ref_points = torch.clamp(self.ref_points + self.hv_margin, max=1.0)

@@ -25,8 +25,8 @@ def _engine(lib, device, B=6, num_x=4, seed=3):
     return eng
 
 
-def _run(lib, device):
-    eng = _engine(lib, device)
+def _run(lib, device, **engine_kw):
+    eng = _engine(lib, device, **engine_kw)
     B, P = eng.B, eng.P
     assert int(eng.n.min()) == 1 and torch.all(eng.pts[:, 0, :2] == 1.0)
     calls = []
@@ -87,6 +87,13 @@ def test_batched_marl_emulated():
 def test_batched_marl_hip():
     with contextlib.redirect_stdout(io.StringIO()):
         _run(tm.load(), "cuda")
+
+
+@pytest.mark.gpu
+def test_batched_marl_hip_small_roof_256_envs():
+    """BASELINE configs[2]'s truss (test/01_small_roof: 16 nodes / 36 elements) at 256 envs: the same invariants"""
+    with contextlib.redirect_stdout(io.StringIO()):
+        _run(tm.load(), "cuda", B=256, num_x=8, seed=7)
 
 
 def _check_actor_infer(lib, device):
