@@ -224,6 +224,14 @@ def main():
     env, G, T, _ = distributed.make_rank_env(topo, B, rank, device=dev, lib=lib, seed=1234, n_action_sets=N_ACTION_SETS)
     elapsed, el_min, el_max, dev_ms = measure(env, G, T, args.steps, args.warmup, dist, distributed)
     st = int(env.status.sum().item())
+    one_launch = bool(env.persistent_rollout)            # the K chained steps of a block ran as ONE persistent launch
+    per_step_launches = None
+    if one_launch and on_gpu and rank == 0 and world == 1:
+        os.environ["TRUSS_ROLLOUT_LAUNCHES"] = "1"        # the same K steps as K launches (what round 1 measured)
+        w, wmin, wmax, d_ms = measure(env, G, T, args.steps, 0, dist, distributed)
+        del os.environ["TRUSS_ROLLOUT_LAUNCHES"]
+        per_step_launches = {"env_steps_per_s": global_envs * args.steps / w, "ms_per_step": w / args.steps * 1e3,
+                             "kernel_us": d_ms * 1e3 / args.steps, "kernel": "truss_step_kernel, one launch per step"}
 
     strong = None
     if world > 1 and args.scaling == "weak":
@@ -303,11 +311,16 @@ def main():
                 # HBM bytes per launch: rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes) of
                 # THIS kernel source, from profiles/r2/pmc_traffic.json; null when the committed profile is of another build
                 "traffic": committed_traffic(ROOT, B, topo.N, topo.E),
-                "kernel": "truss_step_kernel", "kernel_us": kern_s * 1e6,
+                # `kernel_us` / `bytes_per_launch` are PER STEP.  With the persistent rollout one launch of truss_rollout_kernel
+                # plays `steps_per_launch` chained steps (launch duration = steps_per_launch x kernel_us, algorithmic bytes =
+                # steps_per_launch x bytes_per_launch): the rocprofv3 average of that kernel divides the same way
+                "kernel": "truss_rollout_kernel" if one_launch else "truss_step_kernel", "kernel_us": kern_s * 1e6,
+                "steps_per_launch": args.steps if one_launch else 1, "launch_us": kern_s * 1e6 * (args.steps if one_launch else 1),
                 "bytes_per_launch": per_step_bytes,
                 # the other two ceilings SURVEY §8d asks for (algorithmic banded flop count, 1e4 per env-step)
                 "fp64_gflops": 1.0e4 * B / kern_s / 1e9, "fp64_frac_of_78.6_TFLOPs": 1.0e4 * B / kern_s / 78.6e12,
             },
+            "one_launch_per_step": per_step_launches,
             "state_emitting_step": state,
             "nonpositive_pivots": st,
         }

@@ -165,13 +165,20 @@ typedef struct truss_step_args {
 
 int truss_step(const truss_topo_t *t, const truss_step_args_t *args, void *stream);
 
-/* Launch `n_steps` chained steps without returning to the host in between: step s reads design
+/* Run `n_steps` chained steps without returning to the host in between: step s reads design
  * state from buffer (s & 1) and writes buffer ((s+1) & 1); actions for step s are taken at
- * a_geo + (s % n_action_sets) * B*N*2 (resp. a_topo ... *3).  Used by rollouts and bench.py so the
- * per-step host overhead is one kernel launch.  args->y_in/sec_in = buffer 0, y_out/sec_out =
- * buffer 1; all other outputs are overwritten every step. */
+ * a_geo + (s % n_action_sets) * B*N*2 (resp. a_topo ... *3).  args->y_in/sec_in = buffer 0, y_out/sec_out =
+ * buffer 1; all other outputs are overwritten every step (every step writes them: the last step's survive).
+ * This is the `for sol in Pf: for agent: _game_modify(...)` chain of run() (master…:211-260) with the actions known
+ * up front.  Where truss_topo_persistent_rollout() says so the whole chain is ONE launch: every workgroup plays its
+ * envs through all steps with the design state, the per-env constants and the topology tables resident in LDS and
+ * the next step's actions prefetched during the solve (envs are independent: nothing crosses workgroups); otherwise
+ * one launch per step.  Same results either way (bit for bit). */
 int truss_rollout(const truss_topo_t *t, const truss_step_args_t *args, int32_t n_steps,
                   int32_t n_action_sets, void *stream);
+/* 1 when truss_rollout runs plain decode steps of this topology as one persistent launch (0: one launch per step;
+ * also 0 with the environment variable TRUSS_ROLLOUT_LAUNCHES=1, a diagnostic switch read at every call). */
+int truss_topo_persistent_rollout(const truss_topo_t *t);
 
 /* ---- observation tensors ---------------------------------------------------------------------
  * state_data + state_data_not_norm (truss2D_ENV.py:40-193) for the design/analysis a truss_step

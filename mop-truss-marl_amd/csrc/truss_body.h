@@ -249,6 +249,10 @@ struct StepLane {
     bad = 0;
     p_vol = p_dt = p_en = 0.0;
     p_c1 = p_c2 = 0.0f;
+    rs_first_step = 0;
+    rs_y_out = A.y_out;
+    rs_sec_out = A.sec_out;
+    rs_next_geo = rs_next_topo = nullptr;
   }
 
   // ---- phase 0: HBM -> LDS (tables + this env's inputs), clear the band ------------------------
@@ -264,6 +268,27 @@ struct StepLane {
   static constexpr int ECAP = (G * EPL > 128) ? G * EPL : 128;
   static constexpr int NIT = (NCAP / 4 + G - 1) / G;
   static constexpr int EIT = (ECAP / 4 + G - 1) / G;
+  // persistent rollout: the next step's actions, loaded while this step assembles and solves (rollout_prefetch) and parked
+  // in the action rows once the merge scratch that shares their bytes is dead (rollout_stash)
+  tb_u4 pg[2 * NIT], pa[3 * NIT];
+  // what changes from step to step of a persistent rollout (init() takes them from the arguments: a plain step)
+  int rs_first_step;
+  float *rs_y_out;
+  int32_t *rs_sec_out;
+  const float *rs_next_geo, *rs_next_topo;
+  TRUSS_HD void rollout_prefetch(const TopoDev &T, const StepArgsDev &A) {
+    if (rs_next_geo) {     // wave-uniform
+      const size_t bn = (size_t)envc * T.N;
+      row_load<2 * NIT>(rs_next_geo + bn * 2, 2 * (T.N >> 2), pg);
+      row_load<3 * NIT>(rs_next_topo + bn * 3, 3 * (T.N >> 2), pa);
+    }
+  }
+  TRUSS_HD void rollout_stash(const TopoDev &T, const StepArgsDev &A) {
+    if (rs_next_geo) {
+      row_store<2 * NIT>(geosh(T), 2 * (T.N >> 2), pg);
+      row_store<3 * NIT>(tac(T), 3 * (T.N >> 2), pa);
+    }
+  }
 
   TRUSS_HD void stage_row_slow(const void *src, void *dst, int nwords) const {
     const uint32_t *s1 = (const uint32_t *)src;
@@ -350,6 +375,12 @@ struct StepLane {
     const bool decode = !(A.flags & TB_NO_DECODE);
     const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= NCAP && T.E <= ECAP && T.blob_bytes <= BIT_BIG * 64 * 16;
     heads = A.coin ? (A.coin[envc] != 0) : 0;
+    if (rs_first_step != 0) {
+      // persistent rollout, a step after the first: topology tables, constants and the design (the previous step's result)
+      // are in LDS, this step's actions were parked there by rollout_stash -- nothing to fetch
+      band_clear(T);
+      return;
+    }
     if (fast) {
       if (T.blob_bytes <= 3 * 64 * 16) stage_fast<3>(T, A, decode);
       else if (T.blob_bytes <= BIT * 64 * 16) stage_fast<BIT>(T, A, decode);
@@ -1053,8 +1084,8 @@ struct StepLane {
         out_load<NIT>(omu(T), nn, vu);
         out_load<NIT>(omd(T), nn, vw);
       }
-      out_store<NIT>(A.y_out + bn, nn, vy);
-      if (A.sec_out) out_store<EIT>(A.sec_out + be, ne, vs);
+      out_store<NIT>(rs_y_out + bn, nn, vy);
+      if (rs_sec_out) out_store<EIT>(rs_sec_out + be, ne, vs);
       out_store<EIT>(A.q0 + be, ne, vq);
       out_store<EIT>(A.sr + be, ne, vr);
       out_store<(EIT + 3) / 4>(A.comp + be, nc, vc);
@@ -1065,8 +1096,8 @@ struct StepLane {
       }
       return;
     }
-    store_row(A.y_out + bn, ysh(T), 4 * T.N);
-    if (A.sec_out) store_row(A.sec_out + be, secsh(T), 4 * T.E);
+    store_row(rs_y_out + bn, ysh(T), 4 * T.N);
+    if (rs_sec_out) store_row(rs_sec_out + be, secsh(T), 4 * T.E);
     store_row(A.q0 + be, oq0(T), 4 * T.E);
     store_row(A.sr + be, osr(T), 4 * T.E);
     store_row(A.comp + be, ocomp(T), T.E);
@@ -1436,6 +1467,7 @@ struct StepLane {
   PH(phase_sizing(T, A));                                                           \
   if ((T).n_sym_elems > 0 && !((A).flags & TB_NO_DECODE)) { PH(phase_sym_elems(T)); } \
   if (EMIT_) { EMIT_POINT(1); TRUSS_ST(19); } /* compile-time; the sections are final */ \
+  PH_NS(rollout_prefetch(T, A)); /* persistent rollout only: the action rows are consumed, fetch the next step's */ \
   TRUSS_ST(3);                                                                      \
   PH(phase_elements(T, A));                                                         \
   TRUSS_ST(10);                                                                     \
@@ -1573,6 +1605,7 @@ struct StepLane {
   }                                                                                 \
   BAR();                                                                            \
   TRUSS_ST(6);                                                                      \
+  PH_NS(rollout_stash(T, A));                                                       \
   PH(phase_post_elements(T, A));                                                    \
   if (EMIT_) {                                                                      \
     PH(obs_elements_bank(T, A));                                                    \

@@ -222,6 +222,65 @@ __global__ __launch_bounds__(EMIT ? 128 : 64) void truss_step_kernel(const TopoD
 #undef PH_NS
 #undef BAR
 #undef EMIT_POINT
+#undef TB_WAVE_SYNC
+}
+
+// truss_rollout as ONE launch: every workgroup plays its envs through all n_steps chained steps.  Topology tables,
+// per-env constants and the design state (the previous step's result) stay in LDS between steps; the next step's
+// actions are fetched while the current step assembles and solves (rollout_prefetch / rollout_stash), so after the
+// first step no step waits for HBM.  Per step the same result rows are written as by truss_step (design state into
+// the alternating buffers, everything else overwritten), envs are independent: nothing crosses workgroups.
+struct RolloutDev {
+  TopoDev T;
+  StepArgsDev A;                  // the first step's arguments (buffers 0 -> 1, action set 0)
+  int32_t n_steps, n_sets;
+  size_t gstride, tstride;        // floats between consecutive action sets
+};
+template <int G, int WL, int RPL, int EPL>
+__global__ __launch_bounds__(64) void truss_rollout_kernel(const RolloutDev P_) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int W_ = StepLane<G, WL, RPL, EPL, false>::W;
+  constexpr bool EMIT_ = false;
+#define TB_WAVE_SYNC()                                    \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+#define PH(call) \
+  ln.call;       \
+  TB_WAVE_SYNC()
+#define PH_NS(call) ln.call
+#define BAR() TB_WAVE_SYNC()
+#define EMIT_POINT(k) (void)0
+  const int n_steps = P_.n_steps;
+  for (int s = 0; s < n_steps; ++s) {
+    // The arguments are read through a pointer the optimiser cannot see through, once per step: hoisting the ~150
+    // loop-invariant kernel-argument loads (and the addresses derived from them) out of the step loop cost 492 SGPR +
+    // 199 VGPR spills and 760 bytes of scratch per lane; a step re-reads what it needs from the scalar cache instead.
+    // (the pointer keeps the constant address space: through a generic pointer the reads became 500 flat_load's)
+    typedef const char __attribute__((address_space(4))) *tb_kernarg_ptr;
+    tb_kernarg_ptr ka = (tb_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const RolloutDev &P = *(const RolloutDev *)ka;
+    const TopoDev &T = P.T;
+    const StepArgsDev &A = P.A;
+    StepLane<G, WL, RPL, EPL, false> ln;   // per step: no lane state is carried from one step to the next except through LDS
+    ln.init(threadIdx.x, blockIdx.x, T, A, smem);
+    const int nset = (s + 1) % P.n_sets;
+    ln.rs_first_step = s;
+    ln.rs_y_out = (s & 1) ? (float *)A.y_in : A.y_out;          // step s reads buffer s & 1, writes the other one
+    ln.rs_sec_out = (s & 1) ? (int32_t *)A.sec_in : A.sec_out;
+    ln.rs_next_geo = s + 1 < n_steps ? A.a_geo + (size_t)nset * P.gstride : nullptr;
+    ln.rs_next_topo = s + 1 < n_steps ? A.a_topo + (size_t)nset * P.tstride : nullptr;
+    TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
+    TB_WAVE_SYNC();
+  }
+#undef PH
+#undef PH_NS
+#undef BAR
+#undef EMIT_POINT
+#undef TB_WAVE_SYNC
 }
 
 __global__ __launch_bounds__(64) void truss_obs_kernel(const TopoDev T, const ObsArgsDev A) {
@@ -394,6 +453,7 @@ static bool tb_dev_upload(void *dst, const void *src, size_t n) {
 }
 static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *stream);
 static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream);
+static int tb_launch_rollout(const truss_topo *t, const StepArgsDev &A, int n_steps, int n_sets, void *stream);
 
 #include "truss_host.h"
 
@@ -433,6 +493,34 @@ static int hip_run(const truss_topo *t, const StepArgsDev &A, hipStream_t st) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return TRUSS_OK;
+}
+
+template <int G, int WL, int RPL, int EPL>
+static int hip_run_rollout(const truss_topo *t, const StepArgsDev &A, int n_steps, int n_sets, hipStream_t st) {
+  static TbLdsOptIn optin;
+  auto kern = truss_rollout_kernel<G, WL, RPL, EPL>;
+  if (int rc = optin.ensure((const void *)kern)) return rc;
+  RolloutDev Q;
+  Q.T = t->dev;
+  Q.A = A;
+  Q.n_steps = n_steps;
+  Q.n_sets = n_sets;
+  Q.gstride = (size_t)A.B * t->N * 2;
+  Q.tstride = (size_t)A.B * t->N * 3;
+  constexpr int EPB = 64 / G;
+  const unsigned grid = (unsigned)((A.B + EPB - 1) / EPB);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), t->lds_bytes, st, Q);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("rollout kernel launch failed: ") + hipGetErrorString(e));
+  return TRUSS_OK;
+}
+static int tb_launch_rollout(const truss_topo *t, const StepArgsDev &A, int n_steps, int n_sets, void *stream) {
+  const TbVariant &v = kVariants[t->variant];
+#define X(g, wl, r, e) \
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) return hip_run_rollout<g, wl, r, e>(t, A, n_steps, n_sets, (hipStream_t)stream);
+  TRUSS_ROLLOUT_VARIANTS(X)
+#undef X
+  return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled with the persistent rollout");
 }
 
 static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *stream) {

@@ -7,6 +7,8 @@
 //     int  tb_launch_step(const truss_topo *, const StepArgsDev &, bool emit, void *stream);
 //          (emit: the instantiation that also writes the observation tensors; only asked for when dev.emit_ok)
 //     int  tb_launch_obs(const truss_topo *, const ObsArgsDev &, void *stream);
+//     int  tb_launch_rollout(const truss_topo *, const StepArgsDev &, int n_steps, int n_sets, void *stream);
+//          (all chained steps in one launch; only asked for when tb_rollout_one_launch() says the topology allows it)
 // truss_hip.hip implements them with the HIP runtime; tests/emu/truss_emu.cpp with malloc and the
 // CPU lane emulator.
 #pragma once
@@ -43,6 +45,19 @@ struct TbVariant {
 #else
 #define TRUSS_EMIT_VARIANTS(X) X(8, 8, 1, 5) X(16, 8, 1, 3) X(16, 8, 1, 5)
 #endif
+// variants with a persistent rollout kernel (truss_rollout as one launch)
+#ifdef TRUSS_ONLY_DEFAULT_VARIANT
+#define TRUSS_ROLLOUT_VARIANTS(X) X(16, 8, 1, 5)
+#else
+#define TRUSS_ROLLOUT_VARIANTS(X) X(8, 8, 1, 5) X(16, 8, 1, 3) X(16, 8, 1, 5)
+#endif
+static bool tb_variant_rolls(int G, int WL, int RPL, int EPL) {
+#define X(g, wl, r, e) \
+  if (G == g && WL == wl && RPL == r && EPL == e) return true;
+  TRUSS_ROLLOUT_VARIANTS(X)
+#undef X
+  return false;
+}
 static bool tb_variant_emits(int G, int WL, int RPL, int EPL) {
 #define X(g, wl, r, e) \
   if (G == g && WL == wl && RPL == r && EPL == e) return true;
@@ -827,6 +842,22 @@ static int tb_step_dispatch(const truss_topo *t, const StepArgsDev &D, void *str
   return tb_launch_obs(t, O, stream);
 }
 
+// the persistent rollout kernel keeps rows in LDS with the staging fast path's 16-byte accesses: same conditions
+static bool tb_rollout_one_launch(const truss_topo *t, const StepArgsDev &D) {
+  if (tb_env_int("TRUSS_ROLLOUT_LAUNCHES", 0)) return false;          // diagnostic: one launch per step, as in round 1
+  if ((D.flags & (TB_NO_DECODE | TB_EMIT_OBS | TB_CLAMP_INPLACE)) || !D.a_geo) return false;
+  if (!tb_variant_rolls(t->G, t->WL, t->RPL, t->EPL)) return false;
+  const int NPL = (2 * t->EPL + 4) / 5, ncap = std::max(t->G * NPL, 64), ecap = std::max(t->G * t->EPL, 128);
+  return (t->N & 3) == 0 && (t->E & 3) == 0 && t->N <= ncap && t->E <= ecap && t->dev.blob_bytes <= 20 * 64 * 16;
+}
+
+extern "C" int truss_topo_persistent_rollout(const truss_topo_t *t) {
+  if (!t) return 0;
+  StepArgsDev D{};
+  D.a_geo = (float *)1;   // "decode steps with actions": what the query is about
+  return tb_rollout_one_launch(t, D) ? 1 : 0;
+}
+
 extern "C" int truss_step(const truss_topo_t *t, const truss_step_args_t *a, void *stream) {
   StepArgsDev D;
   int rc = tb_make_step_args(t, a, D);
@@ -842,6 +873,7 @@ extern "C" int truss_rollout(const truss_topo_t *t, const truss_step_args_t *a, 
   if (n_steps < 1 || n_action_sets < 1) return tb_fail(TRUSS_EINVAL, "n_steps/n_action_sets < 1");
   if (!a->sec_out) return tb_fail(TRUSS_EINVAL, "rollout needs sec_out");
   if (a->max_up_in) return tb_fail(TRUSS_EINVAL, "rollout recomputes move ranges; pass max_up_in = NULL");
+  if (tb_rollout_one_launch(t, D)) return tb_launch_rollout(t, D, n_steps, n_action_sets, stream);
   const float *ybuf[2] = {a->y_in, a->y_out};
   const int32_t *sbuf[2] = {a->sec_in, a->sec_out};
   const size_t gstride = (size_t)a->n_envs * t->N * 2, tstride = (size_t)a->n_envs * t->N * 3;

@@ -86,6 +86,8 @@ class TrussLib:
         d.truss_topo_solver_info.argtypes = [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         d.truss_topo_fused_obs.restype = C.c_int
         d.truss_topo_fused_obs.argtypes = [_vp]
+        d.truss_topo_persistent_rollout.restype = C.c_int
+        d.truss_topo_persistent_rollout.argtypes = [_vp]
         d.truss_step.restype = C.c_int
         d.truss_step.argtypes = [_vp, C.POINTER(StepArgs), _vp]
         d.truss_rollout.restype = C.c_int

@@ -132,6 +132,11 @@ class BatchedTruss:
         return out
 
     @property
+    def persistent_rollout(self):
+        """True when rollout() runs its chained steps as ONE launch for this topology (state resident in LDS)."""
+        return bool(self.lib.dll.truss_topo_persistent_rollout(self.h))
+
+    @property
     def fused_obs(self):
         """True when step(obs=...) writes the observations from the step's own launch for this topology."""
         return bool(self.lib.dll.truss_topo_fused_obs(self.h))

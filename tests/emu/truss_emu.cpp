@@ -58,6 +58,7 @@ static bool tb_dev_upload(void *dst, const void *src, size_t n) {
 }
 static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *stream);
 static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream);
+static int tb_launch_rollout(const truss_topo *t, const StepArgsDev &A, int n_steps, int n_sets, void *stream);
 
 #include "../../mop-truss-marl_amd/csrc/truss_host.h"
 
@@ -89,6 +90,57 @@ static void emu_run(const truss_topo *t, const StepArgsDev &A) {
 #undef BAR
 #undef EMIT_POINT
   }
+}
+
+// the persistent rollout: all steps of a workgroup back to back on ONE LDS image (no re-poisoning between steps: what a
+// later step reads without re-staging must really have been left there by the previous one)
+template <int G, int WL, int RPL, int EPL>
+static void emu_rollout(const truss_topo *t, StepArgsDev A, int n_steps, int n_sets) {
+  using Lane = EmuLane<StepLane<G, WL, RPL, EPL, false>>;
+  constexpr int W_ = Lane::W;
+  constexpr bool EMIT_ = false;
+  const TopoDev &T = t->dev;
+  const int nblocks = (A.B + Lane::EPB - 1) / Lane::EPB;
+  const size_t gstride = (size_t)A.B * t->N * 2, tstride = (size_t)A.B * t->N * 3;
+  float *ybuf[2] = {(float *)A.y_in, A.y_out};
+  int32_t *sbuf[2] = {(int32_t *)A.sec_in, A.sec_out};
+  float *g0 = A.a_geo, *t0 = A.a_topo;
+  std::vector<char> lds(t->lds_bytes);
+  std::vector<Lane> lanes(64);
+  for (int b = 0; b < nblocks; ++b) {
+    memset(lds.data(), 0xA5, lds.size());
+    for (int s = 0; s < n_steps; ++s) {
+      const int nset = (s + 1) % n_sets;
+      for (int l = 0; l < 64; ++l) {
+        lanes[l].init(l, b, T, A, lds.data());
+        lanes[l].peers = lanes.data();
+        lanes[l].rs_first_step = s;
+        lanes[l].rs_y_out = ybuf[(s + 1) & 1];
+        lanes[l].rs_sec_out = sbuf[(s + 1) & 1];
+        lanes[l].rs_next_geo = s + 1 < n_steps ? g0 + (size_t)nset * gstride : nullptr;
+        lanes[l].rs_next_topo = s + 1 < n_steps ? t0 + (size_t)nset * tstride : nullptr;
+      }
+#define PH(call) \
+  for (auto &ln : lanes) ln.call
+#define PH_NS(call) \
+  for (auto &ln : lanes) ln.call
+#define BAR() (void)0
+#define EMIT_POINT(k) (void)0
+      TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
+#undef PH
+#undef PH_NS
+#undef BAR
+#undef EMIT_POINT
+    }
+  }
+}
+static int tb_launch_rollout(const truss_topo *t, const StepArgsDev &A, int n_steps, int n_sets, void *) {
+  const TbVariant &v = kVariants[t->variant];
+#define X(g, wl, r, e) \
+  if (v.G == g && v.WL == wl && v.RPL == r && v.EPL == e) { emu_rollout<g, wl, r, e>(t, A, n_steps, n_sets); return TRUSS_OK; }
+  TRUSS_ROLLOUT_VARIANTS(X)
+#undef X
+  return tb_fail(TRUSS_EUNSUPPORTED, "variant not compiled with the persistent rollout");
 }
 
 static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, void *) {

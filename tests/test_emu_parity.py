@@ -90,19 +90,24 @@ def test_threebar_analysis_only(lib):
         env.step(torch.zeros(3, 4, 2), torch.zeros(3, 4, 3))
 
 
-def test_rollout_matches_stepwise(lib):
-    topo = synthetic.bench_topology(16, 4)
-    batch = synthetic.random_batch(topo, 10, 3)
-    ag, at = synthetic.random_actions(3, 10, topo.N, 9)
+@pytest.mark.parametrize("case", ["bench", "large_symmetric", "small_bridge", "train_12n"])
+def test_rollout_matches_stepwise(lib, case):
+    """the persistent rollout (all steps of a workgroup on one LDS image, truss_emu.cpp::emu_rollout) vs single steps"""
+    topo, B, sym = {"bench": (synthetic.bench_topology(16, 4), 10, False), "large_symmetric": (tm.TrussTopology.grid(16, "large"), 6, True),
+                    "small_bridge": (tm.TrussTopology.grid(8), 9, False), "train_12n": (tm.TrussTopology.grid(6), 5, False)}[case]
+    batch = synthetic.random_batch(topo, B, 3)
+    ag, at = synthetic.random_actions(3, B, topo.N, 9)
     e1 = pc.make_env(lib, topo, batch)
     e1.analyze(set_normalisers=True)
     e2 = pc.make_env(lib, topo, batch)
     e2.analyze(set_normalisers=True)
+    assert e2.persistent_rollout == (case != "train_12n")
+    coin = torch.tensor((np.random.default_rng(1).random(B) >= 0.5).astype(np.uint8)) if sym else None
     for s in range(5):
-        e1.step(torch.tensor(ag[s % 3]), torch.tensor(at[s % 3]))
-    e2.rollout(torch.tensor(ag), torch.tensor(at), 5)
+        e1.step(torch.tensor(ag[s % 3]), torch.tensor(at[s % 3]), coin)
+    e2.rollout(torch.tensor(ag), torch.tensor(at), 5, coin)
     r1, r2 = e1.results(), e2.results()
-    for k in ("y", "sec", "point", "q0", "sr", "disp", "comp"):
+    for k in ("y", "sec", "point", "q0", "sr", "disp", "comp", "max_up", "max_down", "status"):
         assert np.array_equal(r1[k], r2[k]), k
 
 

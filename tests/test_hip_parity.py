@@ -158,22 +158,35 @@ def test_full_size_properties(lib):
     np.testing.assert_allclose(rb["q0_f64"], 2.0 * ra["q0_f64"], rtol=1e-8, atol=1e-6)
 
 
-def test_rollout_matches_stepwise(lib):
-    topo = synthetic.bench_topology(16, 4)
-    B = 1000
+@pytest.mark.parametrize("case", ["bench_1000", "bench_8200", "large_symmetric", "small_bridge", "train_12n"])
+def test_rollout_matches_stepwise(lib, case, monkeypatch):
+    """truss_rollout (one persistent launch where the topology allows it: design state resident in LDS, next actions
+    prefetched) leaves exactly what the same steps leave one launch at a time -- and what chained launches leave."""
+    topo, B, sym = {"bench_1000": (synthetic.bench_topology(16, 4), 1000, False), "bench_8200": (synthetic.bench_topology(16, 4), 8200, False),
+                    "large_symmetric": (tm.TrussTopology.grid(16, "large"), 300, True), "small_bridge": (tm.TrussTopology.grid(8), 515, False),
+                    "train_12n": (tm.TrussTopology.grid(6), 77, False)}[case]
     batch = synthetic.random_batch(topo, B, 3)
     ag, at = synthetic.random_actions(3, B, topo.N, 9)
-    e1 = pc.make_env(lib, topo, batch)
-    e1.analyze(set_normalisers=True)
-    e2 = pc.make_env(lib, topo, batch)
-    e2.analyze(set_normalisers=True)
+    envs = [pc.make_env(lib, topo, batch) for _ in range(3)]
+    for e in envs:
+        e.analyze(set_normalisers=True)
+    e1, e2, e3 = envs
+    assert e2.persistent_rollout == (case != "train_12n")          # 12 nodes / 26 elements: E % 4 != 0 -> one launch per step
     G, T = torch.tensor(ag, device=e1.device), torch.tensor(at, device=e1.device)
+    coin = torch.tensor((np.random.default_rng(1).random(B) >= 0.5).astype(np.uint8), device=e1.device) if sym else None
     for s in range(7):
-        e1.step(G[s % 3], T[s % 3])
-    e2.rollout(G, T, 7)
-    r1, r2 = e1.results(), e2.results()
-    for k in ("y", "sec", "point", "q0", "sr", "disp", "comp"):
+        e1.step(G[s % 3], T[s % 3], coin)
+    e2.rollout(G, T, 7, coin)
+    monkeypatch.setenv("TRUSS_ROLLOUT_LAUNCHES", "1")
+    assert not e3.persistent_rollout
+    e3.rollout(G, T, 7, coin)
+    r1, r2, r3 = e1.results(), e2.results(), e3.results()
+    assert int(r1["status"].sum()) == 0
+    for k in ("y", "sec", "point", "q0", "sr", "disp", "comp", "max_up", "max_down", "obj", "status"):
         assert np.array_equal(r1[k], r2[k]), k
+        assert np.array_equal(r1[k], r3[k]), k
+    # the other buffer of the double-buffered design holds the design before the last step in all three
+    assert torch.equal(e1.ybuf[e1.cur ^ 1], e2.ybuf[e2.cur ^ 1]) and torch.equal(e1.secbuf[e1.cur ^ 1], e2.secbuf[e2.cur ^ 1])
 
 
 def test_every_kernel_variant(lib, monkeypatch):
