@@ -41,6 +41,32 @@ from .batched import BatchedTruss
 from .topology import TrussTopology
 
 
+_TUNE_UPDATE_GEMMS = False
+
+
+def enable_gemm_tuning(max_ms_per_shape: int = 30, filename: str | None = None):
+    """Let PyTorch's TunableOp choose the library GEMM for the shapes of the MADDPG UPDATE (fixed: batch 32), timed once
+    during the eager warm-up updates that precede the hipGraph capture (BatchedMARL._train).  The weight gradients of the
+    GCN layers (200 x 200 outputs, K = 32 x 16 = 512) otherwise get a single 256 x 224 tile from the library's heuristic:
+    118 us each, half of an update.  The inference GEMMs are left alone: their row count (live (env, member) pairs x nodes)
+    changes every game step and every new shape would be tuned again (11 s for four game steps when tried).
+    No-op on the CPU backend."""
+    global _TUNE_UPDATE_GEMMS
+    if not torch.cuda.is_available():
+        return False
+    t = torch.cuda.tunable
+    t.enable(True)                 # use tuned solutions where a shape has one
+    t.tuning_enable(False)         # ... but time new shapes only inside the update's warm-up
+    t.set_max_tuning_duration(int(max_ms_per_shape))
+    t.set_max_tuning_iterations(20)
+    if filename:
+        t.set_filename(filename)
+    else:
+        t.write_file_on_exit(False)    # no tunableop_results*.csv in the caller's working directory
+    _TUNE_UPDATE_GEMMS = True
+    return True
+
+
 def pareto_graph(pts, n, index, max_front):
     """Batched truss2D_ENV.pareto_state_data (:19-38) + zero padding to P nodes (master…:488-593).
     pts [B,P,4] (rows beyond n ignored), n [B], index [B] -> x_p [B,P,4], A_p [B,P,P] float32."""
@@ -145,9 +171,11 @@ class DeviceReplay:
 class BatchedMARL:
     def __init__(self, topo: TrussTopology, n_envs: int, maddpg, *, max_front: int = 20, lib=None, device=None,
                  replay_capacity: int = 32768, batch_size: int = 32, hv_margin: float = 0.2, seed: int = 0,
-                 pair_capacity: int | None = None):
+                 pair_capacity: int | None = None, tune_update_gemms: bool = True):
         self.topo, self.B, self.P = topo, int(n_envs), int(max_front)
         self.rl = maddpg
+        if tune_update_gemms and (device is None or torch.device(device).type == "cuda"):
+            enable_gemm_tuning()      # library GEMM per (fixed) shape of the update, chosen during its warm-up (23 -> 14 ms per update)
         # members whose candidates fit one cull: P archive rows + 3 candidates per member <= the front kernel's 64 rows
         self.Gm = max(1, min(self.P, (64 - self.P) // 3))
         # (env, member) pairs per pass: the env objects below hold that many designs (3 x as many candidates)
@@ -281,8 +309,14 @@ class BatchedMARL:
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
-                    for _ in range(3):                                   # warm-up on the capture stream
-                        self.rl.train_on_batch(*unpack(bufs))
+                    if _TUNE_UPDATE_GEMMS:
+                        torch.cuda.tunable.tuning_enable(True)           # the update's GEMM shapes are fixed: pick their kernels now
+                    try:
+                        for _ in range(3):                               # warm-up on the capture stream
+                            self.rl.train_on_batch(*unpack(bufs))
+                    finally:
+                        if _TUNE_UPDATE_GEMMS:
+                            torch.cuda.tunable.tuning_enable(False)
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 torch.cuda.synchronize(self.device)
                 def restore():      # weights, Adam moments and loss log back to the state before the warm-up

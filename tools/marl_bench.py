@@ -20,19 +20,22 @@ import master_DDPG_truss2D_MO as M
 import truss2D_RL as RL
 
 
-def run(B=4096, steps=6, train=True, nx=8, profile=False):
+def run(B=4096, steps=6, train=True, nx=8, profile=False, tune=None):
     """nx = bays + 1; 8 = test/01_small_roof (16 nodes, 36 elements); 16 / 32 / 64 / 128 = the size classes of BASELINE configs[4]"""
     dev = "cuda"
+    if tune is None:
+        tune = os.environ.get("MARL_TUNE", "1") != "0"
     topo = tm.TrussTopology.grid(nx)
     rl = RL.MADDPG(M.lr, M.ep, M.epd, M.gamma, M.a_nn, M.c_nn, 100, M.num_agents, M.num_action, M.mu, M.theta, M.sigma, device=dev)
-    eng = marl.BatchedMARL(topo, B, rl, max_front=20, device=dev, replay_capacity=32768, batch_size=32)
+    eng = marl.BatchedMARL(topo, B, rl, max_front=20, device=dev, replay_capacity=32768, batch_size=32, tune_update_gemms=tune)
     x = np.tile(np.arange(nx) * 5.0, 2)
     tar = np.concatenate([np.zeros(nx), 2.0 + 2.0 * np.abs(np.linspace(-1, 1, nx))])
     y0 = np.concatenate([np.zeros(nx), np.full(nx, 8.0)]).astype(np.float32)
     eng.reset(x[None].repeat(B, 0), tar[None].repeat(B, 0), 8.0, 0.3, 0.001 * 5.0 * (nx - 1), 0.0, -120000.0 * 8 / nx, 1.0, y0[None].repeat(B, 0),
               np.full((B, topo.E), 4, np.int32))
     with contextlib.redirect_stdout(io.StringIO()):
-        eng.game_step_all(train=train)                    # warm-up (lazy layers, first launches)
+        for _ in range(2 if tune else 1):
+            eng.game_step_all(train=train)                # warm-up (lazy layers, first launches, GEMM selection)
     torch.cuda.synchronize()
     e0 = eng.env_steps
     if profile:

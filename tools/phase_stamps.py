@@ -37,8 +37,9 @@ def main():
         torch.cuda.synchronize()
         acc = np.zeros(9)
         extra = np.zeros(9)
+        chained = int(os.environ.get("STAMP_STEPS", "1"))     # > 1: the LAST step of a persistent rollout (steady state)
         for _ in range(10):
-            env.rollout(G, T, 1)
+            env.rollout(G, T, chained)
             torch.cuda.synchronize()
             st = (ctypes.c_ulonglong * 16)()
             lib.dll.truss_debug_stamps(st)

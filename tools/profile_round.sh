@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE
   timeout -k 10 200 rocprofv3 --pmc $c -d $OUT/pmc_$tag -o pmc -- $B --steps 20 --warmup 2 > /dev/null 2> $OUT/pmc_$tag.err || { echo "pmc pass $c failed"; tail -3 $OUT/pmc_$tag.err; }
 done
 timeout -k 10 300 python3 bench.py --extras > $OUT/bench_plain.json 2>/dev/null
-python3 tools/reduce_profile.py $OUT > $OUT/summary.json
+python3 tools/reduce_profile.py $OUT 20 > $OUT/summary.json
 head -c 3000 $OUT/summary.json
 # keep only the small files
 find $OUT -name "*.csv" -size +2M -delete
