@@ -61,7 +61,7 @@ def enable_gemm_tuning(max_ms_per_shape: int = 30, filename: str | None = None):
     t.set_max_tuning_iterations(20)
     if filename:
         t.set_filename(filename)
-    else:
+    elif hasattr(t, "write_file_on_exit"):
         t.write_file_on_exit(False)    # no tunableop_results*.csv in the caller's working directory
     _TUNE_UPDATE_GEMMS = True
     return True

@@ -20,6 +20,7 @@ for f in glob.glob(os.path.join(out, "kt", "**", "*.db"), recursive=True):
     c = sqlite3.connect(f)
     for name, in c.execute("select distinct name from kernels where name like '%truss%'"):
         d = [r[0] / 1e3 for r in c.execute("select duration from kernels where name = ?", (name,))]
+        total_us = sum(d)
         if "rollout_kernel" in name:      # launches of different step counts (warm-up 40, timed 400): the timed ones, per step
             try:
                 K = json.loads([l for l in open(os.path.join(out, "bench_under_trace.json")) if l.startswith("{")][-1])["steps"]
@@ -27,18 +28,18 @@ for f in glob.glob(os.path.join(out, "kt", "**", "*.db"), recursive=True):
                 K = 400
             d = [x / K for x in d if x >= 0.5 * max(d)]
             name = name + f"  [per step: launch duration / {K} chained steps]"
-        g = c.execute("select grid_x, workgroup_x, lds_size from kernels where name = ? limit 1", (name,)).fetchone()
+        g = c.execute("select grid_x, workgroup_x, lds_size from kernels where name = ? limit 1", (name.split("  [")[0],)).fetchone()
         res["kernel_stats"].append({"name": name, "calls": len(d), "average_us": statistics.mean(d), "median_us": statistics.median(d),
                                     "min_us": min(d), "max_us": max(d), "stdev_us": statistics.pstdev(d),
-                                    "grid": g[0], "workgroup": g[1], "lds_bytes": g[2]})
+                                    "grid": g[0], "workgroup": g[1], "lds_bytes": g[2], "total_us": total_us})
     tot = c.execute("select sum(duration) from kernels").fetchone()[0]
     for k in res["kernel_stats"]:
-        k["share_of_gpu_time"] = k["average_us"] * k["calls"] * 1e3 / tot
+        k["share_of_gpu_time"] = k["total_us"] * 1e3 / tot
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True):
     c = sqlite3.connect(f)
     vals = {}
     q = ("select counter_name, value, kernel_name, grid_size, workgroup_size, lds_block_size, scratch_size, vgpr_count, "
-         "accum_vgpr_count, sgpr_count from counters_collection where kernel_name like '%truss_step_kernel%'")
+         "accum_vgpr_count, sgpr_count from counters_collection where kernel_name like '%truss_step_kernel%' or kernel_name like '%truss_rollout_kernel%'")
     for cn, v, kn, gs, ws, lds, scr, vg, ag, sg in c.execute(q):
         if gs // ws != 1024:          # the 4096-env launches only (16 lanes per env: 1024 workgroups)
             continue
