@@ -138,10 +138,10 @@ __device__ __forceinline__ void tb_publish(char *lds, int o_flag, int k) {
   __builtin_amdgcn_wave_barrier();
   if (threadIdx.x == 0) *(volatile int *)(lds + o_flag) = k;
 }
-// false = gave up (the compute wave never got there: a fault is being reported elsewhere); the bound keeps the
-// grid draining in every case
+// false = gave up after ~7 s (the compute wave never got there: a fault is being reported elsewhere); the bound keeps
+// the grid draining in every case.  A compute wave publishes within tens of microseconds.
 __device__ __forceinline__ bool tb_await(char *lds, int o_flag, int k) {
-  for (int spin = 0; spin < (1 << 22); ++spin) {
+  for (int spin = 0; spin < (1 << 26); ++spin) {
     const int v = *(volatile int *)(lds + o_flag);
     if (__builtin_amdgcn_readfirstlane(v) >= k) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

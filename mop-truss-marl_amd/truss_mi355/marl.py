@@ -107,22 +107,55 @@ def gcn_aggregate(lib, adj, h, bias, act):
     return out
 
 
+_HPAD = 224     # hidden width the inference GEMMs run at (see actor_infer)
+_pad_cache: dict = {}
+
+
+def _padded_layer(layer, k_in):
+    """(weight [Cout_p, k_in], bias [Cout_p]) of a GCN layer for the padded inference path: hidden outputs (more than 16
+    channels) are widened to _HPAD with zero rows, inputs that are padded hidden activations get zero columns.  Rebuilt
+    when the layer's weights have changed (training updates them in place: tensor version counter)."""
+    w, bvec = layer.lin.weight, layer.bias
+    key = id(layer)
+    ver = (w._version, bvec._version, k_in, w.data_ptr())
+    hit = _pad_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    cout, cin = w.shape
+    cp = _HPAD if 16 < cout <= _HPAD else cout
+    wp = torch.zeros((cp, k_in), dtype=w.dtype, device=w.device)
+    wp[:cout, :cin] = w.detach()
+    bp = torch.zeros((cp,), dtype=bvec.dtype, device=bvec.device)
+    bp[:cout] = bvec.detach()
+    _pad_cache[key] = (ver, wp, bp)
+    return wp, bp
+
+
 def actor_infer(lib, actor, ins):
     """truss2D_RL.multimodes_actor.forward (truss2D_RL.py:49-120) for inference: the dense half of every
-    GCN layer (X W) stays a rocBLAS GEMM over the whole batch, the neighbourhood aggregation + bias +
-    activation is one fused kernel per layer instead of a batched 16x16 GEMM and two elementwise passes."""
+    GCN layer (X W) stays a library GEMM over the whole batch, the neighbourhood aggregation + bias +
+    activation is one fused kernel per layer instead of a batched 16x16 GEMM and two elementwise passes.
+
+    The hidden width is 200; for M ~ 1e5 rows the library's heuristic gives N = 200 a 16 x 256 tile (195 us, 40 TFLOP/s)
+    and N = 224 a proper one (99 us) -- so the hidden activations are carried at 224 channels, the 24 extra ones being
+    exact zeros end to end (zero weight rows, zero bias, relu(0) = 0; zero weight columns in the consuming layer).
+    Same values up to the summation order of the GEMM."""
     x_n, A_n, A_s, A_ts, A_cs, x_p, A_p = ins
 
+    hid = actor.gcn_l1_1.lin.out_features                         # true hidden width (200)
+
     def g(layer, x, a, act="relu"):
-        if isinstance(layer.lin.weight, torch.nn.parameter.UninitializedParameter):   # lazy layers: let the module materialise itself once
+        if isinstance(layer.lin.weight, torch.nn.parameter.UninitializedParameter):   # lazy layers: let the module materialise itself once,
+            k_true = hid if (x.shape[-1] == _HPAD and hid < _HPAD) else x.shape[-1]   # on the un-padded width of its input
             with torch.no_grad():
-                layer(x[:1], a[:1] if a.dim() == 3 else a)
-        return gcn_aggregate(lib, a, layer.lin(x).contiguous(), layer.bias, act)
+                layer(x[:1, :, :k_true], a[:1] if a.dim() == 3 else a)
+        wp, bp = _padded_layer(layer, x.shape[-1])
+        return gcn_aggregate(lib, a, torch.nn.functional.linear(x, wp).contiguous(), bp, act)
 
     a = actor
     x11, x12, x13 = g(a.gcn_l1_1, x_n, A_n), g(a.gcn_l1_2, x_n, A_n), g(a.gcn_l1_3, x_n, A_n)
-    x14 = g(a.gcn_l1_4, x_p, A_p).sum(dim=1)
-    B, H = x14.shape
+    x14 = g(a.gcn_l1_4, x_p, A_p).sum(dim=1)[:, :a.gcn_l1_4.lin.out_features]           # un-padded: the tiling below mixes
+    B, H = x14.shape                                                                     # channels and nodes
     x14 = x14.unsqueeze(-1).expand(B, H, x11.shape[1]).reshape(B, x11.shape[1], H)      # _tile_pool (:87-93)
     x3 = (g(a.gcn_l2_1, x11, A_n) + g(a.gcn_l2_2, x12, A_ts) + g(a.gcn_l2_3, x12, A_cs) + g(a.gcn_l2_4, x13, A_s)
           + g(a.gcn_l2_5, x14.contiguous(), A_n))
