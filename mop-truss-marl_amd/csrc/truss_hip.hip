@@ -591,12 +591,76 @@ __global__ __launch_bounds__(256) void truss_gcn_aggregate_kernel(const float *_
   }
 }
 
+// The same for channel counts that are multiples of 4, sized to the channel count: a thread owns FOUR channels of one
+// graph (16-byte loads / stores) and the threads of a block are dealt over (graph, channel quad) pairs without gaps, so
+// no lane idles whatever C is (thread = channel in 256-wide blocks left 22 % of the lanes idle at C = 200); a block of
+// 256 threads then spans up to 256 / (C / 4) + 2 graphs, whose adjacencies it stages in LDS.
+template <int NMAX>
+__global__ __launch_bounds__(256) void truss_gcn_aggregate4_kernel(const float *__restrict__ adj, long a_stride, const float *h,
+                                                                   const float *__restrict__ bias, float *out, int B, int N, int C4, int act,
+                                                                   int gmax) {
+  extern __shared__ float sA[];                       // [graphs of this block][N][N]
+  const long t0 = (long)blockIdx.x * 256, t = t0 + threadIdx.x;
+  const int g0 = (int)(t0 / C4);
+  int g1 = (int)((t0 + 255) / C4);
+  g1 = g1 < B - 1 ? g1 : B - 1;
+  const int ng = a_stride ? g1 - g0 + 1 : 1, nn = N * N;
+  for (int i = threadIdx.x; i < ng * nn; i += 256) sA[i] = adj[(a_stride ? (size_t)(g0 + i / nn) * a_stride : 0) + i % nn];
+  __syncthreads();
+  const int gph = (int)(t / C4), c4 = (int)(t % C4);
+  if (gph >= B) return;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 *H = (const f4 *)h + ((size_t)gph * N) * C4 + c4;
+  f4 col[NMAX];
+#pragma unroll
+  for (int j = 0; j < NMAX; ++j) col[j] = j < N ? H[(size_t)j * C4] : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+  const f4 bc = bias ? ((const f4 *)bias)[c4] : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+  const float *A = sA + (a_stride ? (gph - g0) * nn : 0);
+  f4 *O = (f4 *)out + ((size_t)gph * N) * C4 + c4;
+  for (int i = 0; i < N; ++i) {
+    f4 acc = bc;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+      const float aij = j < N ? A[i * N + j] : 0.0f;
+      acc[0] = fmaf(aij, col[j][0], acc[0]);
+      acc[1] = fmaf(aij, col[j][1], acc[1]);
+      acc[2] = fmaf(aij, col[j][2], acc[2]);
+      acc[3] = fmaf(aij, col[j][3], acc[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (act == 1) acc[q] = acc[q] > 0.0f ? acc[q] : 0.0f;
+      else if (act == 2) acc[q] = 1.0f / (1.0f + expf(-acc[q]));
+    }
+    O[(size_t)i * C4] = acc;
+  }
+}
+
 extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, const float *h, const float *bias, float *out,
                                    int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act, void *stream) {
   if (!adj || !h || !out) return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: NULL argument");
   if (n_batch < 0 || n_nodes < 1 || n_nodes > 64 || n_channels < 1 || act < 0 || act > 2)
     return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: n_nodes must be 1..64, act 0..2");
   if (n_batch == 0) return TRUSS_OK;
+  if ((n_channels & 3) == 0 && n_nodes <= 32 && (((size_t)h | (size_t)out | (size_t)bias) & 15) == 0) {
+    // channel-quad threads, no idle lanes
+    const int C4 = n_channels / 4;
+    const int gmax = a_batch_stride ? 256 / C4 + 2 : 1;
+    const size_t lds = (size_t)gmax * n_nodes * n_nodes * sizeof(float);
+    const long total = (long)n_batch * C4;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (lds <= 64 * 1024) {
+      if (n_nodes <= 16)
+        hipLaunchKernelGGL(truss_gcn_aggregate4_kernel<16>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, adj, (long)a_batch_stride, h, bias, out,
+                           n_batch, n_nodes, C4, act, gmax);
+      else
+        hipLaunchKernelGGL(truss_gcn_aggregate4_kernel<32>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, adj, (long)a_batch_stride, h, bias, out,
+                           n_batch, n_nodes, C4, act, gmax);
+      hipError_t e4 = hipGetLastError();
+      if (e4 != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("gcn aggregate launch failed: ") + hipGetErrorString(e4));
+      return TRUSS_OK;
+    }
+  }
   dim3 grid((unsigned)n_batch, (unsigned)((n_channels + 255) / 256));
   if (n_nodes <= 16)
     hipLaunchKernelGGL(truss_gcn_aggregate_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, adj, (long)a_batch_stride, h, bias, out, n_nodes, n_channels, act);
