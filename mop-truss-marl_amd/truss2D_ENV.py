@@ -149,8 +149,10 @@ class Game_research04:
             raise np.linalg.LinAlgError("Singular matrix")
         return r
 
-    def _state(self):
-        o = {k: v.cpu().numpy()[0] for k, v in self._bt.observe().items()}
+    def _state(self, obs=None):
+        """observation arrays of env 0: `obs` = what the analysis / step call has just written (TRUSS_F_EMIT_OBS: the
+        reference builds them inside the same _game_modify call, :497-500); None = run the observation kernel"""
+        o = {k: v.cpu().numpy()[0] for k, v in (self._bt.observe() if obs is None else obs).items()}
         return o
 
     # ------------------------------------------------------------------ reference surface
@@ -194,9 +196,9 @@ class Game_research04:
         self._push_constants()
         y, sec = self._design_arrays()
         bt.set_design(y, sec)
-        bt.analyze()
+        ob = bt.analyze(obs=True)
         self._pull(with_design=False)
-        o = self._state()
+        o = self._state(ob)
         x_pf = np.zeros((1, 4), dtype=np.float32)
         x_pf[0][0] = 1
         x_pf[0][1] = 1
@@ -233,12 +235,12 @@ class Game_research04:
         coin = None
         if SYMMETRY is not None:
             coin = torch.tensor([1 if random.random() >= 0.5 else 0], dtype=torch.uint8, device=dev)
-        bt.step(g_t, t_t, coin, mu, md, clamp_inplace=True)
+        ob = bt.step(g_t, t_t, coin, mu, md, clamp_inplace=True, obs=True)   # step + observation tensors: one native call
         # the reference mutates the caller's arrays (truss2D_ENV.py:376-388)
         np.copyto(np.asarray(actions[0]), g_t.cpu().numpy()[0].reshape(np.asarray(actions[0]).shape))
         np.copyto(np.asarray(actions[1]), t_t.cpu().numpy()[0].reshape(np.asarray(actions[1]).shape))
         r = self._pull(with_design=True)
-        o = self._state()
+        o = self._state(ob)
         St_S = [o["x_n"], self._A_n.copy(), o["A_s"], o["A_n_ts"], o["A_n_cs"], self._mask.copy(), None, None,
                 o["nN_x_n"], o["nN_x_e"], self._nC_e.copy()]
         p = r["point"][0]
