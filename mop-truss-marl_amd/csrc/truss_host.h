@@ -49,7 +49,7 @@ struct TbVariant {
 #ifdef TRUSS_ONLY_DEFAULT_VARIANT
 #define TRUSS_ROLLOUT_VARIANTS(X) X(16, 8, 1, 5)
 #else
-#define TRUSS_ROLLOUT_VARIANTS(X) X(8, 8, 1, 5) X(16, 8, 1, 3) X(16, 8, 1, 5)
+#define TRUSS_ROLLOUT_VARIANTS(X) X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(32, 8, 1, 10) X(64, 8, 1, 10)
 #endif
 static bool tb_variant_rolls(int G, int WL, int RPL, int EPL) {
 #define X(g, wl, r, e) \
