@@ -90,10 +90,12 @@ def test_threebar_analysis_only(lib):
         env.step(torch.zeros(3, 4, 2), torch.zeros(3, 4, 3))
 
 
-@pytest.mark.parametrize("case", ["bench", "large_symmetric", "small_bridge", "train_12n"])
-def test_rollout_matches_stepwise(lib, case):
+@pytest.mark.parametrize("case", ["bench", "bench_8_lanes", "large_symmetric", "small_bridge", "train_12n"])
+def test_rollout_matches_stepwise(lib, case, monkeypatch):
     """the persistent rollout (all steps of a workgroup on one LDS image, truss_emu.cpp::emu_rollout) vs single steps"""
-    topo, B, sym = {"bench": (synthetic.bench_topology(16, 4), 10, False), "large_symmetric": (tm.TrussTopology.grid(16, "large"), 6, True),
+    if case == "bench_8_lanes":                  # one team of 8 lanes per env (no two-sided elimination), 10 elements per lane
+        monkeypatch.setenv("TRUSS_LANES", "8")
+    topo, B, sym = {"bench": (synthetic.bench_topology(16, 4), 10, False), "bench_8_lanes": (synthetic.bench_topology(16, 4), 11, False), "large_symmetric": (tm.TrussTopology.grid(16, "large"), 6, True),
                     "small_bridge": (tm.TrussTopology.grid(8), 9, False), "train_12n": (tm.TrussTopology.grid(6), 5, False)}[case]
     batch = synthetic.random_batch(topo, B, 3)
     ag, at = synthetic.random_actions(3, B, topo.N, 9)

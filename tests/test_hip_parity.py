@@ -158,11 +158,14 @@ def test_full_size_properties(lib):
     np.testing.assert_allclose(rb["q0_f64"], 2.0 * ra["q0_f64"], rtol=1e-8, atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["bench_1000", "bench_8200", "large_symmetric", "small_bridge", "train_12n"])
+@pytest.mark.parametrize("case", ["bench_1000", "bench_8200", "bench_8_lanes", "large_symmetric", "small_bridge", "train_12n", "nodes_128"])
 def test_rollout_matches_stepwise(lib, case, monkeypatch):
     """truss_rollout (one persistent launch where the topology allows it: design state resident in LDS, next actions
     prefetched) leaves exactly what the same steps leave one launch at a time -- and what chained launches leave."""
-    topo, B, sym = {"bench_1000": (synthetic.bench_topology(16, 4), 1000, False), "bench_8200": (synthetic.bench_topology(16, 4), 8200, False),
+    if case == "bench_8_lanes":                  # one team of 8 lanes per env (no two-sided elimination), 10 elements per lane
+        monkeypatch.setenv("TRUSS_LANES", "8")
+    topo, B, sym = {"bench_1000": (synthetic.bench_topology(16, 4), 1000, False), "bench_8_lanes": (synthetic.bench_topology(16, 4), 333, False),
+                    "nodes_128": (tm.TrussTopology.grid(64), 70, False), "bench_8200": (synthetic.bench_topology(16, 4), 8200, False),
                     "large_symmetric": (tm.TrussTopology.grid(16, "large"), 300, True), "small_bridge": (tm.TrussTopology.grid(8), 515, False),
                     "train_12n": (tm.TrussTopology.grid(6), 77, False)}[case]
     batch = synthetic.random_batch(topo, B, 3)
