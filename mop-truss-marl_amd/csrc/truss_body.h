@@ -121,12 +121,15 @@ struct TopoDev {
   //     et_mat         : [pair][G][2] x 4 uint16  N x N matrices, row-major chunks of 4 cells: the element joining
   //                      (row, col), or E = none
   //   f_tnxe (LDS, behind the tables every kernel stages: `blob_bytes` of an EMIT launch includes it):
-  //     [iter][G] x 4 uint16 float offsets, as et_xn
+  //     [iter][G] x 4 uint16 float offsets, as et_xn -- when E % 4 == 0.  Otherwise the rows of nN_x_e (21 E floats per env)
+  //     are not 16-byte aligned per env: the table is a plain [21 E] uint16 list and the tensor is written in chunks of
+  //     nxe_cw = 2 (E even) or 1 floats
   int32_t emit_ok;
   const char *etab;
   int32_t o_flag;   // LDS byte offset of the workgroup's progress word (compute wave -> streaming wave)
   int32_t et_xn, et_nxn, et_mat, f_tnxe;
   int32_t nc_xn, nc_nxn, nc_nxe, nc_mat;   // chunks per env
+  int32_t nxe_cw;                          // floats per chunk of nN_x_e: 4, 2 or 1
   // feature bank: float offsets (from the env's LDS base) of the arrays the tables point into; they live in
   // bytes of the env that are dead by the time they are written (band, solver scratch, action rows)
   int32_t b_const;   // [0] = 0, [1] = 1, [2] = 1 / (1 + 1e-6f)
@@ -326,12 +329,16 @@ struct StepLane {
 
   // BI = 16-byte blob units per lane (unrolled): every iteration is a global load and an LDS store for the
   // whole wave whether or not the blob reaches that far, so the common small blob gets its own instance
+  // EW: the element row (sections) by 4-byte words -- rows of E % 4 != 0 elements are not 16-byte aligned per env (the
+  // reference's own training trusses: 12 nodes / 26 elements)
+  static constexpr int EWIT = (ECAP + G - 1) / G;
   template <int BI>
-  TRUSS_HD void stage_fast(const TopoDev &T, const StepArgsDev &A, bool decode) {
+  TRUSS_HD void stage_fast(const TopoDev &T, const StepArgsDev &A, bool decode, bool EW) {
     const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
     {
       const int nb = T.blob_bytes >> 4, nn = T.N >> 2, ne = T.E >> 2;
       tb_u4 vb[BI], vy[NIT], vx[NIT], vt[NIT], vs[EIT], vp[1], vg[2 * NIT], va[3 * NIT];
+      tb_u4 ws[(EWIT + 3) / 4];   // words i of the element row: ws[i / 4][i % 4] (constant indices after unrolling)
       {
         const tb_u4 *s4 = (const tb_u4 *)T.blob;
 #pragma unroll
@@ -343,7 +350,16 @@ struct StepLane {
       row_load<NIT>(A.y_in + bn, nn, vy);
       row_load<NIT>(A.x + bn, nn, vx);
       row_load<NIT>(A.target + bn, nn, vt);
-      row_load<EIT>(A.sec_in + be, ne, vs);
+      if (EW) {
+        const uint32_t *s1 = (const uint32_t *)(A.sec_in + be);
+#pragma unroll
+        for (int i = 0; i < EWIT; ++i) {
+          const int q = g + G * i;
+          ws[i >> 2][i & 3] = s1[q < T.E ? q : T.E - 1];
+        }
+      } else {
+        row_load<EIT>(A.sec_in + be, ne, vs);
+      }
       row_load<1>(A.env_params + (size_t)envc * 8, 4, vp);
       if (decode) {
         row_load<2 * NIT>(A.a_geo + bn * 2, 2 * nn, vg);
@@ -361,7 +377,16 @@ struct StepLane {
       row_store<NIT>(ysh(T), nn, vy);
       row_store<NIT>(xsh(T), nn, vx);
       row_store<NIT>(tgsh(T), nn, vt);
-      row_store<EIT>(secsh(T), ne, vs);
+      if (EW) {
+        uint32_t *d1 = (uint32_t *)secsh(T);
+#pragma unroll
+        for (int i = 0; i < EWIT; ++i) {
+          const int q = g + G * i;
+          d1[q < T.E ? q : T.E - 1] = ws[i >> 2][i & 3];
+        }
+      } else {
+        row_store<EIT>(secsh(T), ne, vs);
+      }
       row_store<1>(par(T), 4, vp);
       if (decode) {
         row_store<2 * NIT>(geosh(T), 2 * nn, vg);
@@ -373,7 +398,8 @@ struct StepLane {
   TRUSS_HD void phase_stage(const TopoDev &T, const StepArgsDev &A) {
     const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
     const bool decode = !(A.flags & TB_NO_DECODE);
-    const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= NCAP && T.E <= ECAP && T.blob_bytes <= BIT_BIG * 64 * 16;
+    const bool fast = (T.N & 3) == 0 && T.N <= NCAP && T.E <= ECAP && T.blob_bytes <= BIT_BIG * 64 * 16;
+    const bool ew = (T.E & 3) != 0;
     heads = A.coin ? (A.coin[envc] != 0) : 0;
     if (rs_first_step != 0) {
       // persistent rollout, a step after the first: topology tables, constants and the design (the previous step's result)
@@ -382,9 +408,9 @@ struct StepLane {
       return;
     }
     if (fast) {
-      if (T.blob_bytes <= 3 * 64 * 16) stage_fast<3>(T, A, decode);
-      else if (T.blob_bytes <= BIT * 64 * 16) stage_fast<BIT>(T, A, decode);
-      else stage_fast<BIT_BIG>(T, A, decode);
+      if (T.blob_bytes <= 3 * 64 * 16) stage_fast<3>(T, A, decode, ew);
+      else if (T.blob_bytes <= BIT * 64 * 16) stage_fast<BIT>(T, A, decode, ew);
+      else stage_fast<BIT_BIG>(T, A, decode, ew);
     } else {
       {
         const tb_u4 *s4 = (const tb_u4 *)T.blob;
@@ -1416,15 +1442,49 @@ struct StepLane {
   // while it waits for the node bank: one LDS round trip less per batch of the last, exposed segment
   TRUSS_HD void obs_nxe_table(const TopoDev &T) {
     if constexpr (EMIT) {
+      if (T.nxe_cw != 4) return;
       const tb_u2 *tab = TB_TAB(tb_u2, TB, T.f_tnxe);
 #pragma unroll
       for (int i = 0; i < IE; ++i) ete[i] = tab[i * G + g];
     }
   }
+  // nN_x_e of a topology whose element count is not a multiple of 4: 8- or 4-byte chunks, four per lane and round
+  TRUSS_HD void emit_nxe_narrow(const TopoDev &T, const StepArgsDev &A) const {
+    if (!A.nxe) return;
+    const float *Lf = (const float *)L;
+    const uint16_t *tab = TB_TAB(uint16_t, TB, T.f_tnxe);
+    float *o = A.nxe + (size_t)env * 21 * T.E;
+    const int nc = T.nc_nxe;
+    if (T.nxe_cw == 2) {
+      for (int q0 = g; q0 < nc; q0 += 4 * G) {
+        tb_f2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = q0 + k * G < nc ? q0 + k * G : nc - 1;
+          const tb_f2 w = {Lf[tab[2 * q]], Lf[tab[2 * q + 1]]};
+          v[k] = w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = q0 + k * G < nc ? q0 + k * G : nc - 1;
+          TB_STREAM_STORE((tb_f2 *)o + q, v[k]);
+        }
+      }
+    } else {
+      for (int q0 = g; q0 < nc; q0 += 4 * G) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = Lf[tab[q0 + k * G < nc ? q0 + k * G : nc - 1]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) TB_STREAM_STORE(o + (q0 + k * G < nc ? q0 + k * G : nc - 1), v[k]);
+      }
+    }
+  }
   TRUSS_HD void obs_emit_raw_rows(const TopoDev &T, const StepArgsDev &A) {
     if constexpr (EMIT) {
       if (!active) return;
-      emit_rows<IE>(A.nxe, (size_t)21 * T.E, T.nc_nxe, ete);
+      if (T.nxe_cw == 4) emit_rows<IE>(A.nxe, (size_t)21 * T.E, T.nc_nxe, ete);
+      else emit_nxe_narrow(T, A);
       emit_rows<IN_>(A.nxn, (size_t)12 * T.N, T.nc_nxn, etn);
     }
   }

@@ -135,7 +135,7 @@ static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res
   D.emit_ok = 0;
   if (!tb_variant_emits(t->G, t->WL, t->RPL, t->EPL) || tb_env_int("TRUSS_NO_FUSED_OBS", 0)) return false;
   const int NPL = (2 * t->EPL + 4) / 5, NF = G * NPL, EF = G * t->EPL;
-  if ((N & 3) || (E & 3) || N > NF || E > EF || !D.has_pairs) return false;
+  if ((N & 3) || N > NF || E > EF || !D.has_pairs) return false;
   // the kernel's compile-time iteration counts (StepLane::IX ...)
   const int IX = (13 * NF / 4 + G - 1) / G, IN_ = (12 * NF / 4 + G - 1) / G, IE = (21 * EF / 4 + G - 1) / G,
             IM = (NF * NF / 4 + G - 1) / G;
@@ -203,7 +203,8 @@ static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res
   }
   D.nc_xn = (int32_t)txn.size() / 4;
   D.nc_nxn = (int32_t)tnxn.size() / 4;
-  D.nc_nxe = (int32_t)tnxe.size() / 4;
+  D.nxe_cw = (E & 3) == 0 ? 4 : (E & 1) == 0 ? 2 : 1;    // 21 E floats per env: 16-, 8- or 4-byte aligned rows
+  D.nc_nxe = (int32_t)tnxe.size() / D.nxe_cw;
   D.nc_mat = (int32_t)tmat.size() / 4;
   // pad to `iters` iterations of G chunks (entries past the end repeat the last chunk); chunk q = iteration q / G, lane q % G
   auto padded = [&](const std::vector<uint16_t> &v, int iters) {
@@ -235,7 +236,7 @@ static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res
     return false;
   }
   D.etab = (const char *)t->etab;
-  D.f_tnxe = (int32_t)tb_push(blob, padded(tnxe, IE));   // LDS-resident, staged by EMIT launches only
+  D.f_tnxe = (int32_t)tb_push(blob, D.nxe_cw == 4 ? padded(tnxe, IE) : tnxe);   // LDS-resident, staged by EMIT launches only
   blob.resize((blob.size() + 15) & ~size_t(15));
   D.emit_ok = 1;
   return true;
@@ -848,7 +849,7 @@ static bool tb_rollout_one_launch(const truss_topo *t, const StepArgsDev &D) {
   if ((D.flags & (TB_NO_DECODE | TB_EMIT_OBS | TB_CLAMP_INPLACE)) || !D.a_geo) return false;
   if (!tb_variant_rolls(t->G, t->WL, t->RPL, t->EPL)) return false;
   const int NPL = (2 * t->EPL + 4) / 5, ncap = std::max(t->G * NPL, 64), ecap = std::max(t->G * t->EPL, 128);
-  return (t->N & 3) == 0 && (t->E & 3) == 0 && t->N <= ncap && t->E <= ecap && t->dev.blob_bytes <= 20 * 64 * 16;
+  return (t->N & 3) == 0 && t->N <= ncap && t->E <= ecap && t->dev.blob_bytes <= 20 * 64 * 16;
 }
 
 extern "C" int truss_topo_persistent_rollout(const truss_topo_t *t) {

@@ -173,6 +173,14 @@ def irregular_topology(seed):
     return tm.TrussTopology(np.array(conn, np.int32), res, g.top, g.pair)
 
 
+def pruned_grid(num_x, k):
+    """the reference's grid truss without its last k '/' braces (every bay keeps its '\\' brace: still stable, same
+    half-bandwidth): element counts of any residue mod 4 at a node count that is a multiple of 4"""
+    g = tm.TrussTopology.grid(num_x)
+    conn = g.conn[: g.E - k] if k else g.conn
+    return tm.TrussTopology(conn, g.res, g.top, g.pair, node_order=g.node_order)
+
+
 def run_random_rollout(lib, num_x, n_extra, B, n_steps, seed, symmetry=None, topo=None, tight=1e-9):
     """Synthetic random-geometry batch, `n_steps` chained steps, native vs oracle every step."""
     irregular = topo is not None
@@ -203,23 +211,32 @@ def run_random_rollout(lib, num_x, n_extra, B, n_steps, seed, symmetry=None, top
     return env
 
 
-def compare_obs(env, o, obs=None):
+def compare_obs(env, o, obs=None, zero_force=0.0):
     """native observation tensors vs the oracle's (float32; 1e-6 relative to the column scale).
-    obs: tensors a step(obs=...) call has written; None = run the observation kernel."""
+    obs: tensors a step(obs=...) call has written; None = run the observation kernel.
+    zero_force > 0 (non-grid topologies, see compare_step): the tension / compression flags of nN_x_e (columns 3, 4) are
+    not compared for members whose force is rounding noise."""
     obs = {k: v.cpu().numpy() for k, v in (env.observe() if obs is None else obs).items()}
     for k in ("x_n", "A_s", "A_n_ts", "A_n_cs", "nN_x_n", "nN_x_e"):
         a, b = obs[k], o[k]
         assert a.shape == b.shape, k
+        if k == "nN_x_e" and zero_force > 0:
+            q = o["fem"]["q0"]
+            noise = np.abs(q) <= zero_force * np.abs(q).max(axis=1, keepdims=True)
+            a = a.copy()
+            a[..., 3:5] = np.where(noise[..., None], b[..., 3:5], a[..., 3:5])
         scale = np.maximum(np.abs(b).reshape(-1, b.shape[-1]).max(axis=0), 1.0)
         err = np.abs(a - b) / scale
         assert float(err.max()) < 2e-6, (k, float(err.max()))
     return obs
 
 
-def run_obs_random(lib, num_x, n_extra, B, seed, fused=False, expect_one_launch=None):
+def run_obs_random(lib, num_x, n_extra, B, seed, fused=False, expect_one_launch=None, topo=None):
     """fused: the observation tensors come out of the step call itself (TRUSS_F_EMIT_OBS) and are compared with the
     oracle AND with what the stand-alone observation kernel writes for the same step."""
-    topo = synthetic.bench_topology(num_x, n_extra) if n_extra else tm.TrussTopology.grid(num_x)
+    custom = topo is not None
+    if topo is None:
+        topo = synthetic.bench_topology(num_x, n_extra) if n_extra else tm.TrussTopology.grid(num_x)
     batch = synthetic.random_batch(topo, B, seed)
     env = make_env(lib, topo, batch)
     env.analyze(set_normalisers=True)
@@ -235,13 +252,14 @@ def run_obs_random(lib, num_x, n_extra, B, seed, fused=False, expect_one_launch=
     env.step(torch.tensor(ag[0], device=env.device), torch.tensor(at[0], device=env.device), obs=got)
     o = O.env_step(ot, batch["x"], batch["y"], batch["sec"], None, None, ag[0], at[0], np.zeros(B), batch["target"],
                    load, batch["y_max"], batch["d_min"], batch["max_def"], batch["is_roof"], int_obj, with_obs=True)
+    zf = 1e-9 if custom else 0.0
     if fused:
-        a = compare_obs(env, o, got)
-        b = compare_obs(env, o)
+        a = compare_obs(env, o, got, zero_force=zf)
+        b = compare_obs(env, o, zero_force=zf)
         for k in a:     # same staged rows; element length by rsqrt-Newton vs sqrt, normalisation by reciprocal vs division
             np.testing.assert_allclose(a[k], b[k], rtol=4e-7, atol=1e-7, err_msg=k)
     else:
-        compare_obs(env, o)
+        compare_obs(env, o, zero_force=zf)
     return env
 
 

@@ -50,7 +50,17 @@ def test_fused_observation_random_emulated(lib):
     pc.run_obs_random(lib, 16, 4, 7, seed=21, fused=True, expect_one_launch=True)    # 32 / 80: the metric topology
     pc.run_obs_random(lib, 16, 0, 5, seed=23, fused=True, expect_one_launch=True)    # 32 / 76
     pc.run_obs_random(lib, 8, 0, 6, seed=24, fused=True, expect_one_launch=True)     # 16 / 36
-    pc.run_obs_random(lib, 6, 0, 3, seed=22, fused=True, expect_one_launch=False)    # 12 / 26: E % 4 != 0 -> two launches
+    pc.run_obs_random(lib, 6, 0, 3, seed=22, fused=True, expect_one_launch=True)     # 12 / 26 (the reference's training trusses):
+                                                                                      # E % 4 == 2 -> nN_x_e in 8-byte chunks
+    pc.run_obs_random(lib, 5, 0, 3, seed=25, fused=True, expect_one_launch=False)    # 10 / 21: N % 4 != 0 -> two launches
+
+
+def test_fused_observation_any_element_count_emulated(lib):
+    """element counts of every residue mod 4: nN_x_e rows (21 E floats per env) are 16-, 8- or 4-byte aligned per env"""
+    for k in range(4):
+        topo = pc.pruned_grid(8, k)                      # 16 nodes, 36 - k elements
+        env = pc.run_obs_random(lib, 0, 0, 5, seed=30 + k, fused=True, expect_one_launch=True, topo=topo)
+        assert env.persistent_rollout
 
 
 def test_symmetric_variants_random(lib):
@@ -103,7 +113,7 @@ def test_rollout_matches_stepwise(lib, case, monkeypatch):
     e1.analyze(set_normalisers=True)
     e2 = pc.make_env(lib, topo, batch)
     e2.analyze(set_normalisers=True)
-    assert e2.persistent_rollout == (case != "train_12n")
+    assert e2.persistent_rollout
     coin = torch.tensor((np.random.default_rng(1).random(B) >= 0.5).astype(np.uint8)) if sym else None
     for s in range(5):
         e1.step(torch.tensor(ag[s % 3]), torch.tensor(at[s % 3]), coin)

@@ -56,7 +56,10 @@ def test_fused_observation_random(lib):
     pc.run_obs_random(lib, 16, 4, 129, seed=21, fused=True, expect_one_launch=True)   # 32 / 80, ragged last workgroup
     pc.run_obs_random(lib, 16, 0, 64, seed=23, fused=True, expect_one_launch=True)    # 32 / 76
     pc.run_obs_random(lib, 8, 0, 65, seed=24, fused=True, expect_one_launch=True)     # 16 / 36
-    pc.run_obs_random(lib, 6, 0, 17, seed=22, fused=True, expect_one_launch=False)    # 12 / 26 -> step + observation kernel
+    pc.run_obs_random(lib, 6, 0, 17, seed=22, fused=True, expect_one_launch=True)     # 12 / 26: nN_x_e in 8-byte chunks
+    pc.run_obs_random(lib, 5, 0, 17, seed=25, fused=True, expect_one_launch=False)    # 10 / 21 -> step + observation kernel
+    for k in range(4):                                                                 # every E mod 4: 16 nodes, 36 - k elements
+        pc.run_obs_random(lib, 0, 0, 70, seed=30 + k, fused=True, expect_one_launch=True, topo=pc.pruned_grid(8, k))
     pc.run_obs_random(lib, 64, 0, 6, seed=64, fused=True, expect_one_launch=False)    # 128 nodes -> two launches
 
 
@@ -174,7 +177,7 @@ def test_rollout_matches_stepwise(lib, case, monkeypatch):
     for e in envs:
         e.analyze(set_normalisers=True)
     e1, e2, e3 = envs
-    assert e2.persistent_rollout == (case != "train_12n")          # 12 nodes / 26 elements: E % 4 != 0 -> one launch per step
+    assert e2.persistent_rollout
     G, T = torch.tensor(ag, device=e1.device), torch.tensor(at, device=e1.device)
     coin = torch.tensor((np.random.default_rng(1).random(B) >= 0.5).astype(np.uint8), device=e1.device) if sym else None
     for s in range(7):
