@@ -32,22 +32,27 @@ static int tb_fail(int code, const std::string &msg) {
 struct TbVariant {
   int G, WL, RPL, EPL;  // lanes per env, window lanes, rows per lane, elements per lane
 };
-#ifdef TRUSS_ONLY_DEFAULT_VARIANT   // diagnostic builds (tools/ablate.sh): compile one kernel only
-#define TRUSS_VARIANTS(X) X(16, 8, 1, 5)
+#ifdef TRUSS_ONLY_DEFAULT_VARIANT   // diagnostic builds (tools/ablate.sh, `make diag`): compile one kernel only
+#ifndef TRUSS_DIAG_VARIANT           // -D'TRUSS_DIAG_VARIANT(X)=X(64,8,1,10)' -DTRUSS_DIAG_NO_EMIT for another one
+#define TRUSS_DIAG_VARIANT(X) X(16, 8, 1, 5)
+#endif
+#define TRUSS_VARIANTS(X) TRUSS_DIAG_VARIANT(X)
 #else
 #define TRUSS_VARIANTS(X) \
   X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(16, 16, 1, 5) X(16, 8, 2, 5) X(4, 4, 2, 20) \
   X(32, 8, 1, 10) X(64, 8, 1, 10) /* large trusses: up to 320 / 640 elements, 128 / 256 nodes (BASELINE config 5) */
 #endif
 // variants that are also compiled with the fused observation emission (StepLane<..., EMIT = true>)
-#ifdef TRUSS_ONLY_DEFAULT_VARIANT
-#define TRUSS_EMIT_VARIANTS(X) X(16, 8, 1, 5)
+#if defined(TRUSS_ONLY_DEFAULT_VARIANT) && defined(TRUSS_DIAG_NO_EMIT)
+#define TRUSS_EMIT_VARIANTS(X)
+#elif defined(TRUSS_ONLY_DEFAULT_VARIANT)
+#define TRUSS_EMIT_VARIANTS(X) TRUSS_DIAG_VARIANT(X)
 #else
 #define TRUSS_EMIT_VARIANTS(X) X(8, 8, 1, 5) X(16, 8, 1, 3) X(16, 8, 1, 5)
 #endif
 // variants with a persistent rollout kernel (truss_rollout as one launch)
 #ifdef TRUSS_ONLY_DEFAULT_VARIANT
-#define TRUSS_ROLLOUT_VARIANTS(X) X(16, 8, 1, 5)
+#define TRUSS_ROLLOUT_VARIANTS(X) TRUSS_DIAG_VARIANT(X)
 #else
 #define TRUSS_ROLLOUT_VARIANTS(X) X(8, 8, 1, 5) X(8, 8, 1, 10) X(16, 8, 1, 3) X(16, 8, 1, 5) X(32, 8, 1, 3) X(32, 8, 1, 10) X(64, 8, 1, 10)
 #endif

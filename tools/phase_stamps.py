@@ -24,7 +24,9 @@ def main():
         path = os.path.abspath(sys.argv[2])   # e.g. an ablated build from tools/ablate.sh
     lib = tm.load(path)
     lib.dll.truss_debug_stamps.argtypes = [ctypes.c_void_p]
-    for label, topo in (("32n/80e", synthetic.bench_topology(16, 4)),):
+    nx = int(os.environ.get("STAMP_NX", "0"))                   # e.g. STAMP_NX=128 with libtruss_mi355_diag64.so: the 256-node grid
+    cases = (("32n/80e", synthetic.bench_topology(16, 4)),) if nx == 0 else ((f"grid {2 * nx}n", tm.TrussTopology.grid(nx)),)
+    for label, topo in cases:
         batch = synthetic.random_batch(topo, B, 1)
         env = tm.BatchedTruss(topo, B, lib=lib)
         env.set_constants(batch["x"], batch["target"], batch["y_max"], batch["d_min"], batch["max_def"],
