@@ -136,9 +136,31 @@ def _clip_each(params, max_norm=1.0):
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
-    # branch-free (no host synchronisation per tensor): the factor is exactly 1.0 where the norm is within bounds
-    norms = torch._foreach_norm(grads)
-    torch._foreach_mul_(grads, [torch.clamp(max_norm / (n + 1e-12), max=1.0) for n in norms])
+    # branch-free (no host synchronisation per tensor): the factor is exactly 1.0 where the norm is within bounds.
+    # Multi-tensor operations throughout: a Python loop over the norms was three tiny launches per parameter tensor,
+    # a third of all launches of an update
+    fac = torch._foreach_add(torch._foreach_norm(grads), 1e-12)
+    torch._foreach_reciprocal_(fac)
+    if max_norm != 1.0:
+        torch._foreach_mul_(fac, max_norm)
+    torch._foreach_clamp_max_(fac, 1.0)
+    torch._foreach_mul_(grads, fac)
+
+
+def _fresh_adam_step(params, lr, eps):
+    """`Adam(params, lr, eps=eps).step()` of an optimiser that is created for this one call (the reference builds a new Adam for
+    every actor update, truss2D_RL.py:629/658/688): with zero moments and step = 1 the bias-corrected moments are g and g^2, so
+    the step is p -= lr * g / (|g| + eps).  Four multi-tensor launches instead of the state allocation (three fills per
+    parameter tensor) and the general update."""
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    grads = [p.grad for p in ps]
+    den = torch._foreach_abs(grads)
+    torch._foreach_add_(den, eps)
+    upd = torch._foreach_div(grads, den)
+    with torch.no_grad():
+        torch._foreach_add_(ps, upd, alpha=-lr)
 
 
 def _allreduce_grads(params, dist):
@@ -337,7 +359,7 @@ class MADDPG:
                 p.grad = g
             _allreduce_grads(ap, self.dist)
             _clip_each(ap)
-            torch.optim.Adam(ap, lr=ag.lr * 0.1, eps=1e-7, capturable=self.device.type == "cuda").step()   # a fresh optimiser every call
+            _fresh_adam_step(ap, ag.lr * 0.1, 1e-7)                                      # a fresh optimiser every call (:629)
 
     def sync_parameters(self, src=0):
         """Data-parallel start: every rank takes rank `src`'s actor / critic / target weights (one broadcast

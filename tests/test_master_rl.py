@@ -211,3 +211,27 @@ def test_gradient_allreduce_keeps_ranks_in_sync():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert diff < 1e-6
+
+
+def test_update_helpers_match_their_per_tensor_definitions():
+    import truss2D_RL as RL
+    """The multi-tensor helpers of the MADDPG update: Keras `clipnorm` per gradient tensor, and the first (= only) step of an
+    Adam optimiser that is created for one call (the reference's actor update, truss2D_RL.py:629)."""
+    torch.manual_seed(0)
+    mk = lambda: [torch.nn.Parameter(torch.randn(4, 5)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(3, 3))]
+    ps, qs = mk(), None
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    for k, (p, q) in enumerate(zip(ps, qs)):
+        g = torch.randn_like(p) * (1e-4, 1.0, 1e3)[k]            # norms below, around and above the clip threshold
+        p.grad, q.grad = g, g.clone()
+    RL._clip_each(ps)
+    for p, q in zip(ps, qs):
+        n = q.grad.norm()
+        want = q.grad * torch.clamp(1.0 / (n + 1e-12), max=1.0)
+        assert torch.equal(p.grad, want)
+        assert p.grad.norm() <= 1.0 + 1e-6
+        q.grad = p.grad.clone()
+    torch.optim.Adam(ps, lr=1e-3, eps=1e-7).step()
+    RL._fresh_adam_step(qs, 1e-3, 1e-7)
+    for p, q in zip(ps, qs):
+        torch.testing.assert_close(q, p, rtol=1e-6, atol=1e-9)
