@@ -53,7 +53,8 @@ class GCNConv(nn.Module):
         self.lin = nn.LazyLinear(channels, bias=False)
         self.bias = nn.Parameter(torch.zeros(channels))
 
-    def forward(self, x, a):
+    def forward(self, x, a, act=None):
+        """act in {None, 'relu', 'sigmoid'}: the layer's activation (Spektral's `activation=`)."""
         # GlorotNormal exactly once: when this call materialises the lazy kernel.  A kernel that came in through
         # load_state_dict / the TensorFlow reader is already materialised and is left alone (a flag on the module is
         # not part of the state_dict: restored kernels were re-initialised on their first forward).
@@ -62,7 +63,8 @@ class GCNConv(nn.Module):
         if fresh:
             nn.init.xavier_normal_(self.lin.weight)
             h = self.lin(x)
-        return torch.matmul(a, h) + self.bias
+        out = torch.matmul(a, h) + self.bias
+        return torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
 
 
 def _tile_pool(x_pool, n_nodes):
@@ -83,22 +85,21 @@ class multimodes_actor(nn.Module):
 
     def forward(self, inputs):
         x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p = inputs
-        relu = torch.relu
-        x_1_1 = relu(self.gcn_l1_1(x_n, A_n))
-        x_1_2 = relu(self.gcn_l1_2(x_n, A_n))
-        x_1_3 = relu(self.gcn_l1_3(x_n, A_n))
-        x_1_4 = relu(self.gcn_l1_4(x_p, A_p)).sum(dim=1)          # GlobalSumPool
+        x_1_1 = self.gcn_l1_1(x_n, A_n, "relu")
+        x_1_2 = self.gcn_l1_2(x_n, A_n, "relu")
+        x_1_3 = self.gcn_l1_3(x_n, A_n, "relu")
+        x_1_4 = self.gcn_l1_4(x_p, A_p, "relu").sum(dim=1)        # GlobalSumPool
         x_1_4 = _tile_pool(x_1_4, x_1_1.shape[1])
-        x_2_1 = relu(self.gcn_l2_1(x_1_1, A_n))
-        x_2_2 = relu(self.gcn_l2_2(x_1_2, A_n_ts))
-        x_2_3 = relu(self.gcn_l2_3(x_1_2, A_n_cs))
-        x_2_4 = relu(self.gcn_l2_4(x_1_3, A_s))
-        x_2_5 = relu(self.gcn_l2_5(x_1_4, A_n))
+        x_2_1 = self.gcn_l2_1(x_1_1, A_n, "relu")
+        x_2_2 = self.gcn_l2_2(x_1_2, A_n_ts, "relu")
+        x_2_3 = self.gcn_l2_3(x_1_2, A_n_cs, "relu")
+        x_2_4 = self.gcn_l2_4(x_1_3, A_s, "relu")
+        x_2_5 = self.gcn_l2_5(x_1_4, A_n, "relu")
         x_3 = x_2_1 + x_2_2 + x_2_3 + x_2_4 + x_2_5
-        x_3_1 = relu(self.gcn_l3_1(x_3, A_n))
-        x_3_2 = relu(self.gcn_l3_2(x_3, A_s))
-        out_1 = torch.sigmoid(self.gcn_l4_1(x_3_1, A_n))
-        out_2 = torch.sigmoid(self.gcn_l4_2(x_3_2, A_n))
+        x_3_1 = self.gcn_l3_1(x_3, A_n, "relu")
+        x_3_2 = self.gcn_l3_2(x_3, A_s, "relu")
+        out_1 = self.gcn_l4_1(x_3_1, A_n, "sigmoid")
+        out_2 = self.gcn_l4_2(x_3_2, A_n, "sigmoid")
         return out_1, out_2
 
 
@@ -115,17 +116,18 @@ class multimodes_critic(nn.Module):
     def forward(self, inputs):
         x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p, self_g, self_t, other_g1, other_t1, other_g2, other_t2 = inputs
         relu = torch.relu
-        x_1_1 = relu(self.l1[0](x_n, A_n))
-        x_1_2 = relu(self.l1[1](x_n, A_n))
-        x_1_3 = relu(self.l1[2](x_n, A_n))
-        x_1_4 = _tile_pool(relu(self.l1[3](x_p, A_p)).sum(dim=1), x_1_1.shape[1])
+        x_1_1 = self.l1[0](x_n, A_n, "relu")
+        x_1_2 = self.l1[1](x_n, A_n, "relu")
+        x_1_3 = self.l1[2](x_n, A_n, "relu")
+        x_1_4 = _tile_pool(self.l1[3](x_p, A_p, "relu").sum(dim=1), x_1_1.shape[1])
         acts = [self_g, self_t, other_g1, other_t1, other_g2, other_t2]
-        x_1_a = [relu(self.l1[4 + i](a, A_n)) for i, a in enumerate(acts)]
-        x2 = [relu(self.l2[0](x_1_1, A_n)), relu(self.l2[1](x_1_2, A_n_ts)), relu(self.l2[2](x_1_2, A_n_cs)),
-              relu(self.l2[3](x_1_3, A_s))]
-        x2 += [relu(self.l2[4 + i](h, A_n)) for i, h in enumerate(x_1_a)]
-        x2.append(relu(self.l2[10](x_1_4, A_n)))
-        q = torch.cat([h.sum(dim=1) for h in x2], dim=-1)            # 11 x GlobalSumPool -> Concatenate
+        x_1_a = [self.l1[4 + i](a, A_n, "relu") for i, a in enumerate(acts)]
+        x2 = [self.l2[0](x_1_1, A_n, "relu"), self.l2[1](x_1_2, A_n_ts, "relu"), self.l2[2](x_1_2, A_n_cs, "relu"),
+              self.l2[3](x_1_3, A_s, "relu")]
+        x2 += [self.l2[4 + i](h, A_n, "relu") for i, h in enumerate(x_1_a)]
+        x2.append(self.l2[10](x_1_4, A_n, "relu"))
+        # 11 x GlobalSumPool -> Concatenate, as one reduction: [B, N, 11, C] summed over the nodes = the 11 pooled vectors side by side
+        q = torch.stack(x2, dim=2).sum(dim=1).flatten(1)
         q = relu(self.dense_1(q))
         q = relu(self.dense_2(q))
         return self.dense_out(q)

@@ -31,6 +31,7 @@ Differences from the per-env loop, all forced by batching and documented here:
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -59,8 +60,11 @@ def enable_gemm_tuning(max_ms_per_shape: int = 30, filename: str | None = None):
     t.tuning_enable(False)         # ... but time new shapes only inside the update's warm-up
     t.set_max_tuning_duration(int(max_ms_per_shape))
     t.set_max_tuning_iterations(20)
+    filename = filename or os.environ.get("TRUSS_GEMM_TUNE_FILE")   # keep / reuse the choices (a profiled run reads them: no tuning)
     if filename:
         t.set_filename(filename)
+        if hasattr(t, "write_file_on_exit"):
+            t.write_file_on_exit(True)
     elif hasattr(t, "write_file_on_exit"):
         t.write_file_on_exit(False)    # no tunableop_results*.csv in the caller's working directory
     _TUNE_UPDATE_GEMMS = True

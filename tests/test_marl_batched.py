@@ -147,3 +147,4 @@ def test_train_graph_matches_eager_updates():
         assert max((a - f).abs().max().item() for a, f in zip(out[-1], first)) > 3 * M.lr
     for a, b in zip(*out):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5)
+

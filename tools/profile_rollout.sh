@@ -7,6 +7,9 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_marl
 rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt0 -o kt -- python3 tools/marl_bench.py 4096 3 0 > $OUT/marl_notrain.json 2> $OUT/kt0.err || { tail -3 $OUT/kt0.err; exit 1; }
+# the update's GEMM choices (TunableOp) are made in an untraced run and read back, so that the trace holds no tuning candidates
+export TRUSS_GEMM_TUNE_FILE=/tmp/truss_tunableop.csv
+timeout -k 10 300 python3 tools/marl_bench.py 4096 1 1 > /dev/null 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o kt -- python3 tools/marl_bench.py 4096 3 1 > $OUT/marl_train.json 2> $OUT/kt1.err || { tail -3 $OUT/kt1.err; exit 1; }
 python3 - <<'PY' > $OUT/summary.json
 import glob, json, sqlite3, statistics
@@ -28,5 +31,7 @@ print(json.dumps({"no_training (warm-up + 3 game steps)": res.get("kt0"), "with_
                   "bench_training_under_trace": line("gpurun_out/prof_marl/marl_train.json"),
                   "note": "rocprofv3 --kernel-trace --stats of tools/marl_bench.py 4096 3 {0,1}: small_roof 16 nodes / 36 elements, 4096 envs"}, indent=1))
 PY
+python3 tools/kernels_by_count.py $OUT/kt1 60 > $OUT/kt1_by_count.txt
+python3 tools/kernels_by_count.py $OUT/kt0 30 > $OUT/kt0_by_count.txt
 head -c 2500 $OUT/summary.json
 find $OUT -name "*.db" -size +4M -delete
