@@ -329,16 +329,12 @@ struct StepLane {
 
   // BI = 16-byte blob units per lane (unrolled): every iteration is a global load and an LDS store for the
   // whole wave whether or not the blob reaches that far, so the common small blob gets its own instance
-  // EW: the element row (sections) by 4-byte words -- rows of E % 4 != 0 elements are not 16-byte aligned per env (the
-  // reference's own training trusses: 12 nodes / 26 elements)
-  static constexpr int EWIT = (ECAP + G - 1) / G;
   template <int BI>
-  TRUSS_HD void stage_fast(const TopoDev &T, const StepArgsDev &A, bool decode, bool EW) {
+  TRUSS_HD void stage_fast(const TopoDev &T, const StepArgsDev &A, bool decode) {
     const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
     {
       const int nb = T.blob_bytes >> 4, nn = T.N >> 2, ne = T.E >> 2;
       tb_u4 vb[BI], vy[NIT], vx[NIT], vt[NIT], vs[EIT], vp[1], vg[2 * NIT], va[3 * NIT];
-      tb_u4 ws[(EWIT + 3) / 4];   // words i of the element row: ws[i / 4][i % 4] (constant indices after unrolling)
       {
         const tb_u4 *s4 = (const tb_u4 *)T.blob;
 #pragma unroll
@@ -350,16 +346,7 @@ struct StepLane {
       row_load<NIT>(A.y_in + bn, nn, vy);
       row_load<NIT>(A.x + bn, nn, vx);
       row_load<NIT>(A.target + bn, nn, vt);
-      if (EW) {
-        const uint32_t *s1 = (const uint32_t *)(A.sec_in + be);
-#pragma unroll
-        for (int i = 0; i < EWIT; ++i) {
-          const int q = g + G * i;
-          ws[i >> 2][i & 3] = s1[q < T.E ? q : T.E - 1];
-        }
-      } else {
-        row_load<EIT>(A.sec_in + be, ne, vs);
-      }
+      row_load<EIT>(A.sec_in + be, ne, vs);
       row_load<1>(A.env_params + (size_t)envc * 8, 4, vp);
       if (decode) {
         row_load<2 * NIT>(A.a_geo + bn * 2, 2 * nn, vg);
@@ -377,16 +364,7 @@ struct StepLane {
       row_store<NIT>(ysh(T), nn, vy);
       row_store<NIT>(xsh(T), nn, vx);
       row_store<NIT>(tgsh(T), nn, vt);
-      if (EW) {
-        uint32_t *d1 = (uint32_t *)secsh(T);
-#pragma unroll
-        for (int i = 0; i < EWIT; ++i) {
-          const int q = g + G * i;
-          d1[q < T.E ? q : T.E - 1] = ws[i >> 2][i & 3];
-        }
-      } else {
-        row_store<EIT>(secsh(T), ne, vs);
-      }
+      row_store<EIT>(secsh(T), ne, vs);
       row_store<1>(par(T), 4, vp);
       if (decode) {
         row_store<2 * NIT>(geosh(T), 2 * nn, vg);
@@ -398,8 +376,7 @@ struct StepLane {
   TRUSS_HD void phase_stage(const TopoDev &T, const StepArgsDev &A) {
     const size_t bn = (size_t)envc * T.N, be = (size_t)envc * T.E;
     const bool decode = !(A.flags & TB_NO_DECODE);
-    const bool fast = (T.N & 3) == 0 && T.N <= NCAP && T.E <= ECAP && T.blob_bytes <= BIT_BIG * 64 * 16;
-    const bool ew = (T.E & 3) != 0;
+    const bool fast = (T.N & 3) == 0 && (T.E & 3) == 0 && T.N <= NCAP && T.E <= ECAP && T.blob_bytes <= BIT_BIG * 64 * 16;
     heads = A.coin ? (A.coin[envc] != 0) : 0;
     if (rs_first_step != 0) {
       // persistent rollout, a step after the first: topology tables, constants and the design (the previous step's result)
@@ -408,9 +385,9 @@ struct StepLane {
       return;
     }
     if (fast) {
-      if (T.blob_bytes <= 3 * 64 * 16) stage_fast<3>(T, A, decode, ew);
-      else if (T.blob_bytes <= BIT * 64 * 16) stage_fast<BIT>(T, A, decode, ew);
-      else stage_fast<BIT_BIG>(T, A, decode, ew);
+      if (T.blob_bytes <= 3 * 64 * 16) stage_fast<3>(T, A, decode);
+      else if (T.blob_bytes <= BIT * 64 * 16) stage_fast<BIT>(T, A, decode);
+      else stage_fast<BIT_BIG>(T, A, decode);
     } else {
       {
         const tb_u4 *s4 = (const tb_u4 *)T.blob;
