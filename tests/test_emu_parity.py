@@ -192,6 +192,11 @@ def test_hip_kernels_use_no_scratch():
     assert len(names) == len(scratch) == len(spills) and len(names) >= 8
     assert sum("truss_step_kernel" in n for n in names) >= 7 and any("truss_obs_kernel" in n for n in names)
     assert all(v == 0 for v in scratch), dict(zip(names, scratch))
+    # the kernels of the metric configuration (16 lanes per env, 5 elements per lane) stay below the 256 architectural VGPRs: every
+    # build that needed AGPR copies there ran the rollout ~5 % slower (tools/experiments/README.md)
+    agprs = dict(zip(names, [int(v) for v in re.findall(r"AGPRs: (\d+)", txt)]))
+    metric = [n for n in names if "ILi16ELi8ELi1ELi5E" in n]
+    assert len(metric) >= 3 and all(agprs[n] == 0 for n in metric), {n: agprs[n] for n in metric}
     # one-row-per-lane kernels (every shipped configuration): no spills at all.  The two-rows-per-lane
     # fallbacks for wide bands may park a register or two in the AGPR file (no memory traffic: scratch is 0).
     assert all(v == 0 for n, v in zip(names, spills) if "ELi2ELi" not in n), dict(zip(names, spills))
