@@ -1681,6 +1681,8 @@ struct ObsArgsDev {
   const double *env_params;
   float *x_n, *A_s, *A_ts, *A_cs, *nxn, *nxe;
   int32_t tile_rows;   // rows of the N x N matrices built per pass (tb_obs_tile_rows)
+  int32_t n_split;     // 1: one workgroup per env walks over the row tiles; > 1: one workgroup per (env, tile) -- large trusses, where a
+                       // batch has few envs and each has hundreds of KB to write (tb_obs_split)
 };
 
 struct ObsLane {
@@ -1688,23 +1690,31 @@ struct ObsLane {
   char *L;
   float maxdef32;
   int is_roof;
+  // split launches (ObsArgsDev::n_split > 1): a workgroup either builds ONE tile of matrix rows (role 1) or the per-node /
+  // per-element rows (role 2); role 0 = everything, tile after tile
+  int role;
+  int minmax_done;
 
-  // LDS: raw[N][13] | mn[13] | mx[13] | (pad to 16) | As[N][N] | Ats[N][N] | Acs[N][N]
+  // LDS: raw[N][13] | mn[13] | mx[13] | part[128] | (pad to 16) | As[TR][N] | Ats[TR][N] | Acs[TR][N]
   TRUSS_HD float *raw() { return (float *)L; }
   TRUSS_HD float *mn(const TopoDev &T) { return raw() + T.N * 13; }
   TRUSS_HD float *mx(const TopoDev &T) { return mn(T) + 13; }
-  TRUSS_HD float *mats(const TopoDev &T) { return (float *)(L + (((size_t)(T.N * 13 + 26) * 4 + 15) & ~(size_t)15)); }
+  TRUSS_HD float *part(const TopoDev &T) { return mx(T) + 13; }   // [2][4][16] partial column minima / maxima
+  TRUSS_HD float *mats(const TopoDev &T) { return (float *)(L + (((size_t)(T.N * 13 + 26 + 128) * 4 + 15) & ~(size_t)15)); }
 
-  TRUSS_HD void init(int lane_, int block, const TopoDev &, const ObsArgsDev &A, char *lds) {
+  TRUSS_HD void init(int lane_, int block, int tile, const TopoDev &, const ObsArgsDev &A, char *lds) {
     lane = lane_;
     env = block;
     L = lds;
+    role = A.n_split <= 1 ? 0 : tile == 0 ? 2 : 1;     // the rows' workgroups (the longest) are dispatched first
+    minmax_done = 0;
     const double *P = A.env_params + (size_t)env * 8;
     maxdef32 = (float)P[2];
     is_roof = P[7] != 0.0;
   }
 
   TRUSS_HD void phase_nodes(const TopoDev &T, const ObsArgsDev &A) {
+    if (role == 1) return;
     const size_t bn = (size_t)env * T.N;
     float *R = raw();
     for (int n = lane; n < T.N; n += 64) {
@@ -1739,6 +1749,22 @@ struct ObsLane {
 
   // rows [r0, r0 + TR) of the three matrices: clear the tile
   TRUSS_HD void phase_tile_clear(const TopoDev &T, const ObsArgsDev &A) {
+    if (role != 1 && !minmax_done) {
+      // column min / max of the raw node features (ENV:102), first half: lane = (column, quarter of the nodes)
+      const int c = lane & 15, q = lane >> 4;
+      if (c < 13) {
+        const float *R = raw();
+        float lo = R[c], hi = R[c];                     // node 0: neutral for both
+        for (int n = q; n < T.N; n += 4) {
+          const float v = R[n * 13 + c];
+          lo = fminf(lo, v);
+          hi = fmaxf(hi, v);
+        }
+        part(T)[q * 16 + c] = lo;
+        part(T)[64 + q * 16 + c] = hi;
+      }
+    }
+    if (role == 2) return;
     float *M = mats(T);
     const int tot = 3 * A.tile_rows * T.N;
     if ((tot & 3) == 0) {                       // 16-byte stores (mats() is 16-byte aligned)
@@ -1753,21 +1779,38 @@ struct ObsLane {
   TRUSS_HD void phase_edges(const TopoDev &T, const ObsArgsDev &A, int r0) {
     const float *R = raw();
     const int TR = A.tile_rows;
-    if (r0 == 0 && lane < 13) {  // column min / max for the normalisation (ENV:102)
-      float lo = R[lane], hi = R[lane];
-      for (int n = 1; n < T.N; ++n) {
-        float v = R[n * 13 + lane];
-        lo = fminf(lo, v);
-        hi = fmaxf(hi, v);
+    if (r0 == 0 && role != 1) {               // second half of the column min / max: the four partial results per column
+      if (lane < 13) {
+        const float *P = part(T);
+        mn(T)[lane] = fminf(fminf(P[lane], P[16 + lane]), fminf(P[32 + lane], P[48 + lane]));
+        mx(T)[lane] = fmaxf(fmaxf(P[64 + lane], P[80 + lane]), fmaxf(P[96 + lane], P[112 + lane]));
       }
-      mn(T)[lane] = lo;
-      mx(T)[lane] = hi;
+      minmax_done = 1;
     }
     const size_t be = (size_t)env * T.E;
     float *As = mats(T), *Ats = As + TR * T.N, *Acs = Ats + TR * T.N;
     const double *AR = TB_TAB(double, T.blob, T.f_area);
     const int16_t *CN = TB_TAB(int16_t, T.blob, T.f_conn);
     const double amax = AR[T.n_sections - 1];
+    if (role == 1) {
+      // one tile of a split launch: its entries come from the rows' incident elements (padded adjacency, 8 slots per node), one
+      // (row, slot) per lane -- not from a scan over all elements by every tile's workgroup
+      const int16_t *ADJ = TB_TAB(int16_t, T.blob, T.f_adj8);
+      for (int i = lane; i < TR * 8; i += 64) {
+        const int n = r0 + (i >> 3);
+        const int e = n < T.N ? ADJ[n * 8 + (i & 7)] : T.E;
+        if (e >= T.E) continue;
+        const int a = CN[2 * e], b = CN[2 * e + 1];
+        const int other = a == n ? b : a;
+        const double area = AR[A.sec[be + e]];
+        const float srv = A.sr[be + e];
+        const float vs = (float)(area / amax);
+        const float val = fminf(srv, 1.0f) * (srv > 1.0f ? 1.0f : 0.5f);
+        As[(n - r0) * T.N + other] = vs;
+        (A.comp[be + e] == 0 ? Ats : Acs)[(n - r0) * T.N + other] = val;
+      }
+      return;
+    }
     for (int e = lane; e < T.E; e += 64) {
       const int a = CN[2 * e], b = CN[2 * e + 1];
       const int s = A.sec[be + e];
@@ -1777,11 +1820,12 @@ struct ObsLane {
       const float vs = (float)(area / amax);
       const float val = fminf(srv, 1.0f) * (srv > 1.0f ? 1.0f : 0.5f);
       float *Aq = cmp == 0 ? Ats : Acs;
-      if (a >= r0 && a < r0 + TR) {          // the element's two entries, each in the tile that holds its row
+      const bool tiles = role != 2;          // the rows' workgroup of a split launch holds no tile
+      if (tiles && a >= r0 && a < r0 + TR) { // the element's two entries, each in the tile that holds its row
         As[(a - r0) * T.N + b] = vs;
         Aq[(a - r0) * T.N + b] = val;
       }
-      if (b >= r0 && b < r0 + TR) {
+      if (tiles && b >= r0 && b < r0 + TR) {
         As[(b - r0) * T.N + a] = vs;
         Aq[(b - r0) * T.N + a] = val;
       }
@@ -1814,7 +1858,7 @@ struct ObsLane {
 
   TRUSS_HD void phase_store(const TopoDev &T, const ObsArgsDev &A, int r0) {
     const float *R = raw();
-    if (A.x_n && r0 == 0) {
+    if (A.x_n && r0 == 0 && role != 1) {
       float *o = A.x_n + (size_t)env * T.N * 13;
       const float *lo = mn(T), *hi = mx(T);
       for (int i = lane; i < T.N * 13; i += 64) {
@@ -1822,6 +1866,7 @@ struct ObsLane {
         TB_STREAM_STORE(&o[i], (R[i] - lo[c]) / (hi[c] - lo[c] + 1e-6f));
       }
     }
+    if (role == 2) return;
     const int rows = (r0 + A.tile_rows <= T.N ? A.tile_rows : T.N - r0);
     const int nn = rows * T.N;                       // floats of this tile
     const float *M = mats(T);
@@ -1842,10 +1887,19 @@ struct ObsLane {
   }
 };
 
-#define TRUSS_OBS_SCHEDULE(PH, PH_NS, T, A)                              \
-  PH(phase_nodes(T, A));                                                 \
-  for (int r0_ = 0; r0_ < (T).N; r0_ += (A).tile_rows) {                 \
+// split launches: the phases a workgroup's role does not have return at once (ObsLane::role; R0 = its tile's first row, 0 for the
+// rows' workgroup)
+#define TRUSS_OBS_SCHEDULE(PH, PH_NS, T, A, R0)                          \
+  if ((A).n_split > 1) {                                                 \
+    PH(phase_nodes(T, A));                                               \
     PH(phase_tile_clear(T, A));                                          \
-    PH(phase_edges(T, A, r0_));                                          \
-    PH(phase_store(T, A, r0_));                                          \
+    PH(phase_edges(T, A, R0));                                           \
+    PH(phase_store(T, A, R0));                                           \
+  } else {                                                               \
+    PH(phase_nodes(T, A));                                               \
+    for (int r0_ = 0; r0_ < (T).N; r0_ += (A).tile_rows) {               \
+      PH(phase_tile_clear(T, A));                                        \
+      PH(phase_edges(T, A, r0_));                                        \
+      PH(phase_store(T, A, r0_));                                        \
+    }                                                                    \
   }

@@ -286,12 +286,13 @@ __global__ __launch_bounds__(64) void truss_rollout_kernel(const RolloutDev P_) 
 __global__ __launch_bounds__(64) void truss_obs_kernel(const TopoDev T, const ObsArgsDev A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ObsLane ln;
-  ln.init(threadIdx.x, blockIdx.x, T, A, smem);
+  ln.init(threadIdx.x, blockIdx.x, blockIdx.y, T, A, smem);
 #define PH(call) \
   ln.call;       \
   __syncthreads()
 #define PH_NS(call) ln.call
-  TRUSS_OBS_SCHEDULE(PH, PH_NS, T, A)
+  const int r0_tile = ln.role == 1 ? ((int)blockIdx.y - 1) * A.tile_rows : 0;   // uniform over the workgroup: the barriers stay convergent
+  TRUSS_OBS_SCHEDULE(PH, PH_NS, T, A, r0_tile)
 #undef PH
 #undef PH_NS
 }
@@ -476,7 +477,7 @@ struct TbLdsOptIn {
 static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *stream) {
   static TbLdsOptIn optin;
   if (int rc = optin.ensure((const void *)truss_obs_kernel)) return rc;
-  hipLaunchKernelGGL(truss_obs_kernel, dim3((unsigned)A.B), dim3(64), tb_obs_lds_bytes(t->N), (hipStream_t)stream, t->dev, A);
+  hipLaunchKernelGGL(truss_obs_kernel, dim3((unsigned)A.B, (unsigned)(A.n_split > 1 ? A.n_split + 1 : 1)), dim3(64), tb_obs_lds_bytes(t->N), (hipStream_t)stream, t->dev, A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("obs kernel launch failed: ") + hipGetErrorString(e));
   return TRUSS_OK;

@@ -77,10 +77,25 @@ static const TbVariant kVariants[] = {
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
-// observation kernel LDS: raw[N][13] | mn[13] | mx[13] | (pad to 16) | three [TR][N] matrix tiles.
+// observation kernel LDS: raw[N][13] | mn[13] | mx[13] | part[128] | (pad to 16) | three [TR][N] matrix tiles.
 // TR = rows per tile: all N rows when the three N x N matrices fit (one pass, 32-node trusses: 12 KB); large
 // trusses are written in row tiles (256 nodes: 3 x 256 KB would not fit any CU).
+static int tb_env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// Trusses of 64 nodes and more: a batch has few envs and each writes 70-870 KB -- one workgroup per (env, tile of rows) with small
+// tiles (64 nodes: 8 rows = 6 KB, 128 nodes: 8 rows, 256 nodes: 4 rows = 12 KB) plus one workgroup per env for the per-node / per-element
+// rows, dispatched first (it is the longest), instead of one workgroup per env walking over 96 KB tiles: 256 envs of 256 nodes were 256
+// waves on 1024 SIMDs, 2.1 TB/s; now 5.8 TB/s (128 nodes: 2.1 -> 5.1, 64 nodes: 3.3 -> 4.0; tools/obs_probe.py).
+// TRUSS_OBS_SPLIT_MIN_N / TRUSS_OBS_TILE_KB: diagnostic overrides for sweeps.
+static inline bool tb_obs_splits(int N) { return N >= tb_env_int("TRUSS_OBS_SPLIT_MIN_N", 64); }
 static inline int tb_obs_tile_rows(int N) {
+  if (tb_obs_splits(N)) {
+    const int tr = (int)(((size_t)tb_env_int("TRUSS_OBS_TILE_KB", N >= 128 ? 12 : 6) * 1024) / ((size_t)3 * N * 4)) & ~1;
+    return tr < 2 ? 2 : tr;
+  }
   const size_t budget = 96 * 1024;
   size_t tr = budget / ((size_t)3 * N * 4);
   if (tr >= (size_t)N) {
@@ -92,13 +107,9 @@ static inline int tb_obs_tile_rows(int N) {
   return tr < 1 ? 1 : (int)tr;
 }
 static inline size_t tb_obs_lds_bytes(int N) {
-  return ((((size_t)(N * 13 + 26) * 4 + 15) & ~(size_t)15) + (size_t)3 * tb_obs_tile_rows(N) * N * 4 + 15) & ~(size_t)15;
+  return ((((size_t)(N * 13 + 26 + 128) * 4 + 15) & ~(size_t)15) + (size_t)3 * tb_obs_tile_rows(N) * N * 4 + 15) & ~(size_t)15;
 }
 
-static int tb_env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 
 template <typename T>
 static size_t tb_push(std::vector<char> &blob, const std::vector<T> &v) {
@@ -845,6 +856,7 @@ static int tb_step_dispatch(const truss_topo *t, const StepArgsDev &D, void *str
   O.nxn = D.nxn;
   O.nxe = D.nxe;
   O.tile_rows = tb_obs_tile_rows(t->N);
+  O.n_split = tb_obs_splits(t->N) ? (t->N + O.tile_rows - 1) / O.tile_rows : 1;
   return tb_launch_obs(t, O, stream);
 }
 
@@ -929,5 +941,6 @@ extern "C" int truss_obs(const truss_topo_t *t, const truss_obs_args_t *a, void 
   D.nxn = a->nN_x_n;
   D.nxe = a->nN_x_e;
   D.tile_rows = tb_obs_tile_rows(t->N);
+  D.n_split = tb_obs_splits(t->N) ? (t->N + D.tile_rows - 1) / D.tile_rows : 1;
   return tb_launch_obs(t, D, stream);
 }

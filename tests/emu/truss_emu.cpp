@@ -163,14 +163,16 @@ static int tb_launch_obs(const truss_topo *t, const ObsArgsDev &A, void *) {
   const TopoDev &T = t->dev;
   std::vector<char> lds(tb_obs_lds_bytes(t->N));
   std::vector<ObsLane> lanes(64);
-  for (int b = 0; b < A.B; ++b) {
-    memset(lds.data(), 0xA5, lds.size());
-    for (int l = 0; l < 64; ++l) lanes[l].init(l, b, T, A, lds.data());
+  for (int b = 0; b < A.B; ++b)
+    for (int tile = 0; tile < (A.n_split > 1 ? A.n_split + 1 : 1); ++tile) {       // grid (B, tiles + the rows' workgroup)
+      memset(lds.data(), 0xA5, lds.size());
+      for (int l = 0; l < 64; ++l) lanes[l].init(l, b, tile, T, A, lds.data());
+      const int r0_tile = lanes[0].role == 1 ? (tile - 1) * A.tile_rows : 0;
 #define PH(call) \
   for (auto &ln : lanes) ln.call
-    TRUSS_OBS_SCHEDULE(PH, PH, T, A)
+      TRUSS_OBS_SCHEDULE(PH, PH, T, A, r0_tile)
 #undef PH
-  }
+    }
   return TRUSS_OK;
 }
 

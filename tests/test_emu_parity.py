@@ -223,7 +223,8 @@ def test_large_trusses_emulated(num_x, tight):
     assert int(env.status.sum()) == 0
 
 
-@pytest.mark.parametrize("num_x", [64, 128])
+@pytest.mark.parametrize("num_x", [32, 64, 68, 128])
 def test_observation_tensors_large_emulated(num_x):
-    """128 / 256 nodes: the three N x N matrices are written in row tiles (2 resp. 8 passes)"""
+    """64 / 128 / 136 / 256 nodes: the three N x N matrices are written in row tiles, one workgroup per (env, tile) and one for the
+    per-node / per-element rows: 8 tiles of 8 rows, 16 of 8, 20 of 6 + one of 4, 64 of 4"""
     pc.run_obs_random(pc.emu_lib(), num_x, 0, 2, seed=num_x)

@@ -242,6 +242,6 @@ def test_large_trusses(lib, num_x, tight):
     assert int(env.status.sum()) == 0
 
 
-@pytest.mark.parametrize("num_x", [64, 128])
+@pytest.mark.parametrize("num_x", [32, 64, 68, 128])
 def test_observation_tensors_large(lib, num_x):
     pc.run_obs_random(lib, num_x, 0, 6, seed=num_x)
