@@ -11,7 +11,7 @@ round-robin buckets across GPUs so each rank gets the same class mix":
   * on a rank, the buckets of one class are merged into one `BatchedTruss` (one launch per class and step);
   * classes are independent; `streams=True` puts each class's launches on its own HIP stream.  Measured on one MI355X
     (2048 / 1024 / 512 / 256 envs of 32 / 64 / 128 / 256 nodes): 190 us per pool step with streams against 163 us on one
-    stream (the launches do not overlap enough to pay for the event hand-shakes), 348 against 365 us with the observation
+    stream (the launches do not overlap enough to pay for the event hand-shakes), 252 against 265 us with the observation
     tensors -- hence off by default;
   * `step / analyze / observe` fan out over the classes; `point`, `status`, `obj` come back concatenated in POOL ORDER
     (class-major, bucket order), with `index()` mapping pool rows back to (class, local env).
