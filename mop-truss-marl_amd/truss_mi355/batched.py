@@ -11,7 +11,7 @@ Tensors live on the device that matches the loaded library's backend: "hip" -> a
 """
 from __future__ import annotations
 
-import ctypes as C
+import contextlib
 
 import numpy as np
 import torch
@@ -19,14 +19,7 @@ import torch
 from . import _lib, ops
 from .topology import TrussTopology
 
-
-import contextlib
-
 _NULL_CTX = contextlib.nullcontext()
-
-
-def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
 
 
 class BatchedTruss:
@@ -91,11 +84,6 @@ class BatchedTruss:
     @property
     def sec(self):
         return self.secbuf[self.cur]
-
-    def _stream(self):
-        if self.device.type == "cuda":
-            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        return None
 
     def _on_device(self):
         """Native launches go to the CURRENT HIP device: make it this env's device for the call (a no-op
