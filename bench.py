@@ -95,7 +95,7 @@ def cpu_baseline():
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         pool.map(_cpu_worker, [(100 + i, 8, 1) for i in range(cores)])           # imports, first touch
-        n_steps = 8
+        n_steps = 64       # ~1 s of wall time on 16 cores = ~15 s of CPU work
         t0 = time.perf_counter()
         res = pool.map(_cpu_worker, [(1234 + i, shard, n_steps) for i in range(cores)])
         wall = time.perf_counter() - t0
