@@ -99,7 +99,8 @@ def gcn_aggregate(lib, adj, h, bias, act):
     """act(adj @ h + bias) through the fused HIP kernel `truss_gcn_aggregate` (inference only, float32).
     adj [N,N] (shared) or [B,N,N]; h [B,N,C] contiguous; act in {None,'relu','sigmoid'}."""
     B, N, Cc = h.shape
-    if N > 64:     # large graphs: a 256 x 256 x C batched GEMM is what rocBLAS is good at; the fused kernel is for the small ones
+    if N > 32:     # larger graphs: a batched N x N x C GEMM is what rocBLAS is good at (64 nodes x 1024 graphs: 75 us against 182 us
+                   # for the thread-per-channel kernel, tools/agg_probe.py); the channel-quad kernel covers N <= 32 (16 nodes: 56 vs 305 us)
         out = torch.matmul(adj, h) + bias
         return torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
     from . import ops
