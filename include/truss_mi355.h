@@ -260,6 +260,18 @@ int truss_front(const truss_front_args_t *args, void *stream);
 int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, const float *h, const float *bias, float *out,
                         int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act, void *stream);
 
+/* The same aggregation for graphs whose adjacency is known to be zero outside a fixed sparsity pattern -- the truss's own
+ * connectivity plus the diagonal, which is the pattern of every node-graph adjacency the reference builds (A_n, A_s, A_n_ts,
+ * A_n_cs: truss2D_ENV.py:40-193): out[b][i][c] = act(sum_k A[b][i][nbr[i][k]] H[b][nbr[i][k]][c] + bias[c]), k < k_nbr,
+ * instead of a sum over all n_nodes columns (256-node trusses: 9 terms instead of 256).  `adj` stays the DENSE [n_nodes][n_nodes]
+ * matrix (per env or shared, as above): only the listed entries are read.  nbr: int16 [n_nodes][k_nbr] device table, ascending
+ * column indices per row, -1 = unused slot; k_nbr <= 16.  n_channels must be a multiple of 4, h / out / bias 16-byte aligned.
+ * Any n_nodes <= 32767.  `out` must NOT alias `h` (rows are read by their neighbours' threads).
+ */
+int truss_gcn_aggregate_sparse(const float *adj, int64_t a_batch_stride, const int16_t *nbr, int32_t k_nbr, const float *h,
+                               const float *bias, float *out, int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -637,6 +637,79 @@ __global__ __launch_bounds__(256) void truss_gcn_aggregate4_kernel(const float *
   }
 }
 
+// Sparse-pattern variant: thread = (graph, row, channel quad), flat over the launch; a row's <= 16 listed neighbours instead of
+// all N columns.  The H rows a thread reads are 16-byte loads that the threads of a row issue contiguously (C floats); a graph's
+// rows are re-read by their neighbours' threads from L2 / L1, so HBM sees H once and `out` once.
+template <int KR>   // neighbours per round: all loads of a round are in flight together (KR = 12 covers a truss row in one round)
+__global__ __launch_bounds__(256) void truss_gcn_aggregate_sparse_kernel(const float *__restrict__ adj, long a_stride,
+                                                                         const int16_t *__restrict__ nbr, int K, const float *__restrict__ h,
+                                                                         const float *__restrict__ bias, float *__restrict__ out, long total,
+                                                                         int N, int C4, int act) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int c4 = (int)(t % C4);
+  const long r = t / C4;
+  const int i = (int)(r % N);
+  const long b = r / N;
+  const float *Arow = adj + b * a_stride + (long)i * N;
+  const f4 *Hb = (const f4 *)h + (size_t)b * N * C4 + c4;
+  const int16_t *nb = nbr + (long)i * K;
+  f4 acc = bias ? ((const f4 *)bias)[c4] : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int k0 = 0; k0 < K; k0 += KR) {
+    int j[KR];
+    float a[KR];
+    f4 hv[KR];
+#pragma unroll
+    for (int q = 0; q < KR; ++q) {
+      j[q] = k0 + q < K ? (int)nb[k0 + q] : -1;
+      const int jc = j[q] < 0 ? i : j[q];
+      a[q] = Arow[jc];
+      hv[q] = Hb[(size_t)jc * C4];
+    }
+#pragma unroll
+    for (int q = 0; q < KR; ++q) {
+      if (j[q] < 0) continue;
+      acc[0] = fmaf(a[q], hv[q][0], acc[0]);
+      acc[1] = fmaf(a[q], hv[q][1], acc[1]);
+      acc[2] = fmaf(a[q], hv[q][2], acc[2]);
+      acc[3] = fmaf(a[q], hv[q][3], acc[3]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (act == 1) acc[q] = acc[q] > 0.0f ? acc[q] : 0.0f;
+    else if (act == 2) acc[q] = 1.0f / (1.0f + expf(-acc[q]));
+  }
+  ((f4 *)out)[t] = acc;
+}
+
+extern "C" int truss_gcn_aggregate_sparse(const float *adj, int64_t a_batch_stride, const int16_t *nbr, int32_t k_nbr, const float *h,
+                                          const float *bias, float *out, int32_t n_batch, int32_t n_nodes, int32_t n_channels,
+                                          int32_t act, void *stream) {
+  if (!adj || !nbr || !h || !out) return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate_sparse: NULL argument");
+  if (n_batch < 0 || n_nodes < 1 || n_nodes > 32767 || k_nbr < 1 || k_nbr > 16 || n_channels < 4 || (n_channels & 3) || act < 0 || act > 2)
+    return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate_sparse: n_nodes 1..32767, k_nbr 1..16, n_channels a multiple of 4, act 0..2");
+  if ((((size_t)h | (size_t)out | (size_t)bias) & 15) != 0 || h == out)
+    return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate_sparse: h / out / bias must be 16-byte aligned, out must not alias h");
+  if (n_batch == 0) return TRUSS_OK;
+  const int C4 = n_channels / 4;
+  const long total = (long)n_batch * n_nodes * C4;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (k_nbr <= 4)
+    hipLaunchKernelGGL(truss_gcn_aggregate_sparse_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, adj, (long)a_batch_stride, nbr, k_nbr, h,
+                       bias, out, total, n_nodes, C4, act);
+  else if (k_nbr <= 8)
+    hipLaunchKernelGGL(truss_gcn_aggregate_sparse_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, adj, (long)a_batch_stride, nbr, k_nbr, h,
+                       bias, out, total, n_nodes, C4, act);
+  else
+    hipLaunchKernelGGL(truss_gcn_aggregate_sparse_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, adj, (long)a_batch_stride, nbr, k_nbr, h,
+                       bias, out, total, n_nodes, C4, act);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("gcn sparse aggregate launch failed: ") + hipGetErrorString(e));
+  return TRUSS_OK;
+}
+
 extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, const float *h, const float *bias, float *out,
                                    int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act, void *stream) {
   if (!adj || !h || !out) return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: NULL argument");

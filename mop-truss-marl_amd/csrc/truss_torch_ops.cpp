@@ -1,6 +1,6 @@
 // truss_torch_ops.cpp -- PyTorch custom operators in front of the C ABI of include/truss_mi355.h.
 //
-//   torch.ops.truss_mi355.step / rollout / obs / front / gcn_aggregate
+//   torch.ops.truss_mi355.step / rollout / obs / front / gcn_aggregate / gcn_aggregate_sparse
 //
 // The reference's hot path runs inside TensorFlow ops on its side of the loop (truss2D_RL.py:328-354); here the env
 // step itself is an operator of the host framework: tensors in, tensors mutated in place, launched on the stream the
@@ -25,6 +25,8 @@ struct Backend {
   int (*obs)(const truss_topo_t *, const truss_obs_args_t *, void *) = nullptr;
   int (*front)(const truss_front_args_t *, void *) = nullptr;
   int (*gcn)(const float *, int64_t, const float *, const float *, float *, int32_t, int32_t, int32_t, int32_t, void *) = nullptr;
+  int (*gcn_sparse)(const float *, int64_t, const int16_t *, int32_t, const float *, const float *, float *, int32_t, int32_t, int32_t,
+                    int32_t, void *) = nullptr;
   const char *(*last_error)(void) = nullptr;
   bool device = false;   // true: the HIP library (tensors must be on a cuda device)
 };
@@ -212,11 +214,32 @@ void gcn_aggregate(int64_t lib, int64_t stream, const at::Tensor &adj, const at:
 }
 void gcn_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &, const OT &, const at::Tensor &, int64_t) {}
 
+// the same over a fixed sparsity pattern (nbr [N, K] int16: the columns that may be non-zero in row i) == truss_gcn_aggregate_sparse
+void gcn_aggregate_sparse(int64_t lib, int64_t stream, const at::Tensor &adj, const at::Tensor &nbr, const at::Tensor &h, const OT &bias,
+                          const at::Tensor &out, int64_t act) {
+  const Backend &b = backend(lib);
+  TORCH_CHECK(b.gcn_sparse, "truss_mi355: the bound native library has no truss_gcn_aggregate_sparse");
+  TORCH_CHECK(h.dim() == 3 && out.sizes() == h.sizes(), "truss_mi355: h / out must be [B, N, C] of equal shape");
+  const int64_t B = h.size(0), N = h.size(1), C = h.size(2);
+  TORCH_CHECK((adj.dim() == 2 || adj.dim() == 3) && adj.size(-1) == N && adj.size(-2) == N && (adj.dim() == 2 || adj.size(0) == B),
+              "truss_mi355: adj must be [N, N] or [B, N, N]");
+  TORCH_CHECK(nbr.dim() == 2 && nbr.size(0) == N, "truss_mi355: nbr must be [N, K]");
+  const float *pa = ptr<const float>(b, adj, at::kFloat, "adj");
+  const int16_t *pn = ptr<const int16_t>(b, nbr, at::kShort, "nbr");
+  const float *ph = ptr<const float>(b, h, at::kFloat, "h");
+  const float *pb = ptr<const float>(b, bias, at::kFloat, "bias", C);
+  float *po = ptr<float>(b, out, at::kFloat, "out");
+  check_rc(b, b.gcn_sparse(pa, adj.dim() == 3 ? N * N : 0, pn, (int32_t)nbr.size(1), ph, pb, po, (int32_t)B, (int32_t)N, (int32_t)C,
+                           (int32_t)act, (void *)stream),
+           "truss_gcn_aggregate_sparse");
+}
+void gcn_sparse_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &, const at::Tensor &, const OT &, const at::Tensor &, int64_t) {}
+
 }  // namespace
 
 // Bind the entry points of a loaded native library (addresses from ctypes) under a small index.
-extern "C" int truss_torch_bind(int lib, void *step_fn, void *rollout_fn, void *obs_fn, void *front_fn, void *gcn_fn, void *last_error_fn,
-                                int is_device) {
+extern "C" int truss_torch_bind(int lib, void *step_fn, void *rollout_fn, void *obs_fn, void *front_fn, void *gcn_fn, void *gcn_sparse_fn,
+                                void *last_error_fn, int is_device) {
   if (lib < 0 || lib >= (int)g_backends.size() || !step_fn) return -1;
   Backend &b = g_backends[lib];
   b.step = (decltype(b.step))step_fn;
@@ -224,6 +247,7 @@ extern "C" int truss_torch_bind(int lib, void *step_fn, void *rollout_fn, void *
   b.obs = (decltype(b.obs))obs_fn;
   b.front = (decltype(b.front))front_fn;
   b.gcn = (decltype(b.gcn))gcn_fn;
+  b.gcn_sparse = (decltype(b.gcn_sparse))gcn_sparse_fn;
   b.last_error = (decltype(b.last_error))last_error_fn;
   b.device = is_device != 0;
   return 0;
@@ -246,6 +270,7 @@ TORCH_LIBRARY(truss_mi355, m) {
   m.def("front(int lib, int stream, int max_front, int flags, Tensor points, Tensor n_points, Tensor? ref_points, "
         "Tensor(a!)? front_idx, Tensor(b!)? n_front, Tensor(c!)? hv_front, Tensor(d!)? hv_all, Tensor(e!)? metrics) -> ()");
   m.def("gcn_aggregate(int lib, int stream, Tensor adj, Tensor h, Tensor? bias, Tensor(a!) out, int act) -> ()");
+  m.def("gcn_aggregate_sparse(int lib, int stream, Tensor adj, Tensor nbr, Tensor h, Tensor? bias, Tensor(a!) out, int act) -> ()");
 }
 TORCH_LIBRARY_IMPL(truss_mi355, CPU, m) {   // the emulator library of the test-suite binds here
   m.impl("step", step);
@@ -253,6 +278,7 @@ TORCH_LIBRARY_IMPL(truss_mi355, CPU, m) {   // the emulator library of the test-
   m.impl("obs", obs);
   m.impl("front", front);
   m.impl("gcn_aggregate", gcn_aggregate);
+  m.impl("gcn_aggregate_sparse", gcn_aggregate_sparse);
 }
 TORCH_LIBRARY_IMPL(truss_mi355, CUDA, m) {  // = HIP on ROCm: the product library
   m.impl("step", step);
@@ -260,6 +286,7 @@ TORCH_LIBRARY_IMPL(truss_mi355, CUDA, m) {  // = HIP on ROCm: the product librar
   m.impl("obs", obs);
   m.impl("front", front);
   m.impl("gcn_aggregate", gcn_aggregate);
+  m.impl("gcn_aggregate_sparse", gcn_aggregate_sparse);
 }
 TORCH_LIBRARY_IMPL(truss_mi355, Meta, m) {  // tracing: every operator only mutates its outputs
   m.impl("step", step_meta);
@@ -267,4 +294,5 @@ TORCH_LIBRARY_IMPL(truss_mi355, Meta, m) {  // tracing: every operator only muta
   m.impl("obs", obs_meta);
   m.impl("front", front_meta);
   m.impl("gcn_aggregate", gcn_meta);
+  m.impl("gcn_aggregate_sparse", gcn_sparse_meta);
 }

@@ -95,20 +95,31 @@ def pareto_graph(pts, n, index, max_front):
     return x, d[:, :, None] * A * d[:, None, :]
 
 
-def gcn_aggregate(lib, adj, h, bias, act):
-    """act(adj @ h + bias) through the fused HIP kernel `truss_gcn_aggregate` (inference only, float32).
-    adj [N,N] (shared) or [B,N,N]; h [B,N,C] contiguous; act in {None,'relu','sigmoid'}."""
+def gcn_aggregate(lib, adj, h, bias, act, nbr=None):
+    """act(adj @ h + bias) through the fused HIP kernels `truss_gcn_aggregate` / `truss_gcn_aggregate_sparse` (inference only, float32).
+    adj [N,N] (shared) or [B,N,N]; h [B,N,C] contiguous; act in {None,'relu','sigmoid'}.
+    nbr: int16 [N,K] device table of the columns that can be non-zero in each row of `adj` (TrussTopology.neighbor_table());
+    with it, graphs above 32 nodes sum over those K columns only (tools/agg_probe.py: 64 nodes 39 us against 74 us for the
+    library's batched GEMM + bias + activation, 256 nodes 42 against 104; at 32 nodes the dense channel-quad kernel is as fast, at 16 faster)."""
     B, N, Cc = h.shape
-    if N > 32:     # larger graphs: a batched N x N x C GEMM is what rocBLAS is good at (64 nodes x 1024 graphs: 75 us against 182 us
-                   # for the thread-per-channel kernel, tools/agg_probe.py); the channel-quad kernel covers N <= 32 (16 nodes: 56 vs 305 us)
+    from . import ops
+    code = {None: 0, "relu": 1, "sigmoid": 2}[act]
+    if nbr is not None and N > 32 and Cc % 4 == 0 and nbr.shape[1] <= 16:
+        adj = adj.contiguous()
+        if adj.dim() == 3 and adj.shape[0] == 1:
+            adj = adj[0]
+        out = torch.empty_like(h)
+        ops.call(ops.namespace().gcn_aggregate_sparse, ops.bind(lib), ops.stream_of(h.device), adj, nbr, h, bias, out, code)
+        return out
+    if N > 32:     # larger graphs without a pattern: a batched N x N x C GEMM is what rocBLAS is good at (64 nodes x 1024 graphs: 75 us
+                   # against 182 us for the thread-per-channel kernel, tools/agg_probe.py); the channel-quad kernel covers N <= 32
         out = torch.matmul(adj, h) + bias
         return torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
-    from . import ops
     adj = adj.contiguous()
     if adj.dim() == 3 and adj.shape[0] == 1:
         adj = adj[0]
     out = torch.empty_like(h)
-    ops.call(ops.namespace().gcn_aggregate, ops.bind(lib), ops.stream_of(h.device), adj, h, bias, out, {None: 0, "relu": 1, "sigmoid": 2}[act])
+    ops.call(ops.namespace().gcn_aggregate, ops.bind(lib), ops.stream_of(h.device), adj, h, bias, out, code)
     return out
 
 
@@ -136,7 +147,7 @@ def _padded_layer(layer, k_in):
     return wp, bp
 
 
-def actor_infer(lib, actor, ins):
+def actor_infer(lib, actor, ins, nbr=None):
     """truss2D_RL.multimodes_actor.forward (truss2D_RL.py:49-120) for inference: the dense half of every
     GCN layer (X W) stays a library GEMM over the whole batch, the neighbourhood aggregation + bias +
     activation is one fused kernel per layer instead of a batched 16x16 GEMM and two elementwise passes.
@@ -144,7 +155,8 @@ def actor_infer(lib, actor, ins):
     The hidden width is 200; for M ~ 1e5 rows the library's heuristic gives N = 200 a 16 x 256 tile (195 us, 40 TFLOP/s)
     and N = 224 a proper one (99 us) -- so the hidden activations are carried at 224 channels, the 24 extra ones being
     exact zeros end to end (zero weight rows, zero bias, relu(0) = 0; zero weight columns in the consuming layer).
-    Same values up to the summation order of the GEMM."""
+    Same values up to the summation order of the GEMM.
+    nbr: the truss's neighbour table on the device (see gcn_aggregate) for the layers over the node graph."""
     x_n, A_n, A_s, A_ts, A_cs, x_p, A_p = ins
 
     hid = actor.gcn_l1_1.lin.out_features                         # true hidden width (200)
@@ -155,7 +167,7 @@ def actor_infer(lib, actor, ins):
             with torch.no_grad():
                 layer(x[:1, :, :k_true], a[:1] if a.dim() == 3 else a)
         wp, bp = _padded_layer(layer, x.shape[-1])
-        return gcn_aggregate(lib, a, torch.nn.functional.linear(x, wp).contiguous(), bp, act)
+        return gcn_aggregate(lib, a, torch.nn.functional.linear(x, wp).contiguous(), bp, act, None if a is A_p else nbr)
 
     a = actor
     x11, x12, x13 = g(a.gcn_l1_1, x_n, A_n), g(a.gcn_l1_2, x_n, A_n), g(a.gcn_l1_3, x_n, A_n)
@@ -226,6 +238,7 @@ class BatchedMARL:
         A_n, mask = topo.normalized_adjacency()
         self.A_n = torch.tensor(A_n, device=dev)[None]
         self.mask = torch.tensor(mask, device=dev)[None]
+        self.nbr = torch.tensor(topo.neighbor_table(), device=dev)     # sparsity pattern of every node-graph adjacency (actor inference)
         self.pts = torch.zeros((B, P, 4), dtype=torch.float64, device=dev)
         self.arch_y = torch.zeros((B, P, N), dtype=torch.float32, device=dev)
         self.arch_sec = torch.zeros((B, P, E), dtype=torch.int32, device=dev)
@@ -303,7 +316,7 @@ class BatchedMARL:
         with torch.no_grad():
             for ag in self.rl.agents:
                 g, t = actor_infer(self.lib, ag.actor_model, [actor_in[0], self.A_n[0], actor_in[2], actor_in[3], actor_in[4],
-                                                              actor_in[5], actor_in[6]])
+                                                              actor_in[5], actor_in[6]], nbr=self.nbr)
                 if explore:                                           # truss2D_RL.OUNoise.gen_noise per scalar (:41-48)
                     for out, noises in ((g, ag.noise_geo), (t, ag.noise_topo)):
                         for j, nz in enumerate(noises):

@@ -146,6 +146,20 @@ class TrussTopology:
         D = np.diag(d)
         return np.matmul(D, np.matmul(A, D)).astype(np.float32), mask
 
+    def neighbor_table(self):
+        """int16 [N, K]: per node the columns in which a node-graph adjacency of this truss (A_n, A_s, A_n_ts, A_n_cs,
+        truss2D_ENV.py:40-193) can be non-zero -- the node itself and the far ends of its members -- ascending, padded with -1.
+        The sparsity pattern for `truss_gcn_aggregate_sparse`."""
+        nb = [{n} for n in range(self.N)]
+        for a, b in self.conn.tolist():
+            nb[a].add(b)
+            nb[b].add(a)
+        K = max(len(s) for s in nb)
+        tab = np.full((self.N, K), -1, np.int16)
+        for n, s in enumerate(nb):
+            tab[n, :len(s)] = sorted(s)
+        return tab
+
     def incidence(self):
         c = np.zeros((self.E, self.N), np.float32)
         c[np.arange(self.E), self.conn[:, 0]] = 1

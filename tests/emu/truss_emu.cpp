@@ -302,6 +302,32 @@ extern "C" int truss_front(const truss_front_args_t *a, void *) {
   return TRUSS_OK;
 }
 
+extern "C" int truss_gcn_aggregate_sparse(const float *adj, int64_t a_batch_stride, const int16_t *nbr, int32_t k_nbr, const float *h,
+                                          const float *bias, float *out, int32_t n_batch, int32_t n_nodes, int32_t n_channels,
+                                          int32_t act, void *) {
+  if (!adj || !nbr || !h || !out) return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate_sparse: NULL argument");
+  if (n_batch < 0 || n_nodes < 1 || n_nodes > 32767 || k_nbr < 1 || k_nbr > 16 || n_channels < 4 || (n_channels & 3) || act < 0 || act > 2)
+    return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate_sparse: n_nodes 1..32767, k_nbr 1..16, n_channels a multiple of 4, act 0..2");
+  if ((((size_t)h | (size_t)out | (size_t)bias) & 15) != 0 || h == out)
+    return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate_sparse: h / out / bias must be 16-byte aligned, out must not alias h");
+  const int N = n_nodes, C = n_channels;
+  for (int b = 0; b < n_batch; ++b) {
+    const float *A = adj + (size_t)b * a_batch_stride, *H = h + (size_t)b * N * C;
+    for (int i = 0; i < N; ++i)
+      for (int c = 0; c < C; ++c) {
+        float acc = bias ? bias[c] : 0.0f;
+        for (int k = 0; k < k_nbr; ++k) {
+          const int j = nbr[i * k_nbr + k];
+          if (j >= 0) acc = std::fmaf(A[i * N + j], H[(size_t)j * C + c], acc);
+        }
+        if (act == 1) acc = acc > 0.0f ? acc : 0.0f;
+        else if (act == 2) acc = 1.0f / (1.0f + std::exp(-acc));
+        out[((size_t)b * N + i) * C + c] = acc;
+      }
+  }
+  return TRUSS_OK;
+}
+
 extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, const float *h, const float *bias, float *out,
                                    int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act, void *) {
   if (!adj || !h || !out) return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: NULL argument");

@@ -117,6 +117,55 @@ def _check_actor_infer(lib, device):
         torch.testing.assert_close(marl.gcn_aggregate(lib, adj, h, bias, act), f(torch.matmul(adj, h) + bias), rtol=2e-5, atol=2e-6)
 
 
+def _check_sparse_aggregate(lib, device):
+    """truss_gcn_aggregate_sparse: the sum over a truss's neighbour table equals the dense A @ H + b wherever the adjacency is zero
+    outside that pattern (every node-graph adjacency of the reference is); through actor_infer on a 64-node truss too."""
+    torch.manual_seed(3)
+    for nx, B, C in ((8, 7, 8), (32, 5, 224), (128, 2, 12)):
+        topo = tm.TrussTopology.grid(nx)
+        N = topo.N
+        tab = topo.neighbor_table()
+        assert tab.shape[0] == N and tab.shape[1] <= 9 and np.all(np.diff(np.where(tab < 0, 1 << 14, tab), axis=1) > -1)
+        pat = np.zeros((N, N), bool)
+        for i in range(N):
+            pat[i, tab[i][tab[i] >= 0]] = True
+        A_n, mask = topo.normalized_adjacency()
+        assert np.all(pat[A_n != 0]) and np.all(pat[mask != 0]) and pat.sum() == 2 * topo.E + N
+        nbr = torch.tensor(tab, device=device)
+        patt = torch.tensor(pat, device=device)
+        h, bias = torch.randn(B, N, C, device=device), torch.randn(C, device=device)
+        for adj in (torch.tensor(A_n, device=device), torch.rand(B, N, N, device=device) * patt):
+            for act, f in ((None, lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
+                out = torch.empty_like(h)
+                from truss_mi355 import ops
+                ops.call(ops.namespace().gcn_aggregate_sparse, ops.bind(lib), ops.stream_of(h.device), adj, nbr, h, bias, out,
+                         {None: 0, "relu": 1, "sigmoid": 2}[act])
+                torch.testing.assert_close(out, f(torch.matmul(adj, h) + bias), rtol=2e-5, atol=2e-6)
+    # through the actor: 64 nodes, adjacencies on the truss's pattern
+    topo = tm.TrussTopology.grid(32)
+    N, B, P = topo.N, 3, 20
+    A_n, mask = topo.normalized_adjacency()
+    m = torch.tensor(mask, device=device)
+    actor = RL.multimodes_actor(40, 2, 3).to(device)
+    r = lambda *s: torch.rand(*s, device=device)
+    ins = [r(B, N, 13), torch.tensor(A_n, device=device), r(B, N, N) * m, r(B, N, N) * m, r(B, N, N) * m, r(B, P, 4),
+           torch.softmax(torch.randn(B, P, P, device=device), -1)]
+    with torch.no_grad():
+        ref = actor([ins[0], ins[1][None].expand(B, -1, -1)] + ins[2:])
+        got = marl.actor_infer(lib, actor, ins, nbr=torch.tensor(topo.neighbor_table(), device=device))
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+
+
+def test_sparse_aggregate_emulated():
+    _check_sparse_aggregate(pc.emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_sparse_aggregate_hip():
+    _check_sparse_aggregate(tm.load(), "cuda")
+
+
 def test_actor_infer_emulated():
     _check_actor_infer(pc.emu_lib(), "cpu")
 

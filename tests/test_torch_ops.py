@@ -12,7 +12,7 @@ import parity_common as pc
 
 def test_operators_are_registered_with_mutation_schemas():
     ns = ops.namespace()
-    for name in ("step", "rollout", "obs", "front", "gcn_aggregate"):
+    for name in ("step", "rollout", "obs", "front", "gcn_aggregate", "gcn_aggregate_sparse"):
         assert hasattr(ns, name), name
     sch = str(ns.step.default._schema)
     assert sch.startswith("truss_mi355::step(int lib, int topo, int stream, int flags, int n_envs, int n_nodes, int n_elems")

@@ -33,6 +33,12 @@ for N, B in ((16, 10000), (32, 4096), (48, 2048), (64, 1024), (128, 512), (256, 
             import truss_mi355.ops as ops
             o = torch.empty_like(h)
             r["fused_us"] = timed(lambda: ops.call(ops.namespace().gcn_aggregate, ops.bind(lib), ops.stream_of(dev), adj.contiguous(), h, bias, o, 1))
+        if tag == "shared" or True:
+            topo = tm.TrussTopology.grid(N // 2)
+            nbr = torch.tensor(topo.neighbor_table(), device=dev)
+            import truss_mi355.ops as ops
+            o2 = torch.empty_like(h)
+            r["sparse_us"] = timed(lambda: ops.call(ops.namespace().gcn_aggregate_sparse, ops.bind(lib), ops.stream_of(dev), adj.contiguous(), nbr, h, bias, o2, 1))
         r["MB"] = round(2 * h.numel() * 4 / 1e6, 1)
         out[f"N{N}_B{B}_{tag}"] = r
 print(json.dumps(out))
