@@ -76,7 +76,6 @@ def run(tm, synthetic, lib, dev, topo, env, G, T, args, B):
                                                            "nonpositive_pivots": int(eb.status.sum().item())}
     # BASELINE configs[4]: the mixed 32-256-node pool on one GPU (one BatchedTruss per size class, one stream per class)
     from truss_mi355 import pool
-    import time
     classes = pool.grid_classes([16, 32, 64, 128], [2048, 1024, 512, 256])
     for tag, streams in (("mixed_pool_32_64_128_256_nodes", True), ("mixed_pool_same_one_stream", False)):
         p = pool.MixedTrussPool(classes, bucket_envs=64, device=dev, lib=lib, streams=streams)

@@ -10,7 +10,6 @@ from __future__ import annotations
 import os
 import time
 
-import numpy as np
 import torch
 
 from . import synthetic

@@ -14,15 +14,9 @@ so R agrees to ~1e-6 relative.
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 
 from . import _lib
-
-
-def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
 
 
 def front_hv(points, n_points, ref_points=None, max_front=0, lib=None, stream=None):
