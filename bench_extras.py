@@ -1,6 +1,6 @@
 """bench.py --extras: secondary measurements on one GPU (rank 0): the reference-exact E = 76 topology, the
 stand-alone observation kernel and the two-launch state-emitting step (what TRUSS_F_EMIT_OBS replaced), BASELINE
-configs[1]'s small bridge, configs[4]'s large size classes, and the batched MADDPG rollout of configs[2]."""
+configs[1]'s small bridge, configs[4]'s large size classes and mixed sweep, and the batched MADDPG rollout of configs[2]."""
 import torch
 
 NUM_X = 16
@@ -112,4 +112,9 @@ def run(tm, synthetic, lib, dev, topo, env, G, T, args, B):
     for tag, train in (("marl_small_roof_4096", True), ("marl_small_roof_4096_no_training", False)):
         r = marl_bench.run(4096, 4, train, 8)
         extras[tag] = {k: r[k] for k in ("env_steps_per_s", "env_steps", "seconds", "mean_front", "game_steps")}
+    # BASELINE configs[4]: the mixed 32 / 64 / 128 / 256-node Pareto sweep with one set of agents (tools/marl_mixed_bench.py)
+    import marl_mixed_bench
+    for tag, train in (("marl_mixed_sweep", True), ("marl_mixed_sweep_no_training", False)):
+        r = marl_mixed_bench.run(train=train)
+        extras[tag] = {k: r[k] for k in ("env_steps_per_s", "env_steps", "seconds", "envs_per_class", "game_steps")}
     return extras
