@@ -637,6 +637,76 @@ __global__ __launch_bounds__(256) void truss_gcn_aggregate4_kernel(const float *
   }
 }
 
+// Slab variant (dense or sparse pattern): a block owns a 128-byte channel slab (8 quads) of GB whole graphs.  It stages the slab of
+// H in LDS with full-line loads (8 threads = one 128-byte line), then every (graph, row, quad) item sums its terms from LDS and
+// stores 16 bytes -- 8 items = one whole line.  HBM sees H once and `out` once; the neighbours' rows come from LDS, not from L2.
+// nbr == nullptr: dense, the K = N columns in order.
+__global__ __launch_bounds__(256) void truss_gcn_aggregate_slab_kernel(const float *__restrict__ adj, long a_stride,
+                                                                       const int16_t *__restrict__ nbr, int K, const float *__restrict__ h,
+                                                                       const float *__restrict__ bias, float *__restrict__ out, int B, int N,
+                                                                       int C4, int GB, int act) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ f4 sH[];                              // [GB][N][8]
+  const int slab = blockIdx.y, q0 = slab * 8;
+  const int nq = C4 - q0 < 8 ? C4 - q0 : 8;               // quads of this slab (the last one may be short)
+  const int b0 = blockIdx.x * GB;
+  const int gb = B - b0 < GB ? B - b0 : GB;
+  const int items = gb * N * 8;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int q = it & 7, r = it >> 3;                    // r = g * N + row
+    if (q < nq) sH[it] = ((const f4 *)h)[((size_t)b0 * N + r) * C4 + q0 + q];
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int q = it & 7, r = it >> 3;
+    if (q >= nq) continue;
+    const int g = r / N, i = r - g * N;
+    const float *Arow = adj + (size_t)(b0 + g) * a_stride + (size_t)i * N;
+    const f4 *Hg = sH + (size_t)g * N * 8 + q;
+    f4 acc = bias ? ((const f4 *)bias)[q0 + q] : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (nbr) {
+      const int16_t *nb = nbr + (size_t)i * K;
+      for (int k = 0; k < K; ++k) {     // (an unrolled round of 12 with all loads in flight was slower: 45 against 34 us at 64 nodes)
+        const int j = nb[k];
+        if (j < 0) continue;
+        const float a = Arow[j];
+        const f4 hv = Hg[j * 8];
+        acc[0] = fmaf(a, hv[0], acc[0]);
+        acc[1] = fmaf(a, hv[1], acc[1]);
+        acc[2] = fmaf(a, hv[2], acc[2]);
+        acc[3] = fmaf(a, hv[3], acc[3]);
+      }
+    } else {
+      for (int j = 0; j < N; ++j) {
+        const float a = Arow[j];
+        const f4 hv = Hg[j * 8];
+        acc[0] = fmaf(a, hv[0], acc[0]);
+        acc[1] = fmaf(a, hv[1], acc[1]);
+        acc[2] = fmaf(a, hv[2], acc[2]);
+        acc[3] = fmaf(a, hv[3], acc[3]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (act == 1) acc[c] = acc[c] > 0.0f ? acc[c] : 0.0f;
+      else if (act == 2) acc[c] = 1.0f / (1.0f + expf(-acc[c]));
+    }
+    ((f4 *)out)[((size_t)b0 * N + r) * C4 + q0 + q] = acc;
+  }
+}
+// launch helper: false when the shape does not suit the slab kernel (the callers' other kernels take over)
+static bool tb_launch_gcn_slab(const float *adj, int64_t a_stride, const int16_t *nbr, int K, const float *h, const float *bias, float *out,
+                               int B, int N, int C, int act, hipStream_t st) {
+  if ((C & 3) || (((size_t)h | (size_t)out | (size_t)bias) & 15) != 0) return false;   // (out may alias h: a block reads its whole tile first)
+  const int GB = std::max(1, 256 / (8 * N));
+  const size_t lds = (size_t)GB * N * 8 * 16;
+  if (lds > 48 * 1024) return false;
+  const int C4 = C / 4;
+  dim3 grid((unsigned)((B + GB - 1) / GB), (unsigned)((C4 + 7) / 8));
+  hipLaunchKernelGGL(truss_gcn_aggregate_slab_kernel, grid, dim3(256), lds, st, adj, (long)a_stride, nbr, K, h, bias, out, B, N, C4, GB, act);
+  return true;
+}
+
 // Sparse-pattern variant: thread = (graph, row, channel quad), flat over the launch; a row's <= 16 listed neighbours instead of
 // all N columns.  The H rows a thread reads are 16-byte loads that the threads of a row issue contiguously (C floats); a graph's
 // rows are re-read by their neighbours' threads from L2 / L1, so HBM sees H once and `out` once.
@@ -693,6 +763,14 @@ extern "C" int truss_gcn_aggregate_sparse(const float *adj, int64_t a_batch_stri
   if ((((size_t)h | (size_t)out | (size_t)bias) & 15) != 0 || h == out)
     return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate_sparse: h / out / bias must be 16-byte aligned, out must not alias h");
   if (n_batch == 0) return TRUSS_OK;
+  // up to 128 nodes the slab kernel (rows from LDS: 33-36 us at 64 / 128 nodes against 40-42; at 256 nodes a block walks 8 rounds
+  // over its 32 KB tile and loses: 52 against 42 us, tools/agg_probe.py)
+  if (n_nodes <= tb_env_int("TRUSS_GCN_SLAB_MAX_N", 128) &&
+      tb_launch_gcn_slab(adj, a_batch_stride, nbr, k_nbr, h, bias, out, n_batch, n_nodes, n_channels, act, (hipStream_t)stream)) {
+    hipError_t es = hipGetLastError();
+    if (es != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("gcn slab aggregate launch failed: ") + hipGetErrorString(es));
+    return TRUSS_OK;
+  }
   const int C4 = n_channels / 4;
   const long total = (long)n_batch * n_nodes * C4;
   const dim3 grid((unsigned)((total + 255) / 256));
@@ -716,6 +794,13 @@ extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, con
   if (n_batch < 0 || n_nodes < 1 || n_nodes > 64 || n_channels < 1 || act < 0 || act > 2)
     return tb_fail(TRUSS_EINVAL, "truss_gcn_aggregate: n_nodes must be 1..64, act 0..2");
   if (n_batch == 0) return TRUSS_OK;
+  // 17..64 nodes: the slab kernel (32 nodes: 58-61 us against 73-84 for the channel-quad kernel below, 64 nodes: 44 against 182 for
+  // the thread-per-channel kernel and 75 for rocBLAS + bias + activation); <= 16 nodes: the channel-quad kernel (56 against 74 us)
+  if (n_nodes > 16 && tb_launch_gcn_slab(adj, a_batch_stride, nullptr, n_nodes, h, bias, out, n_batch, n_nodes, n_channels, act, (hipStream_t)stream)) {
+    hipError_t es = hipGetLastError();
+    if (es != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("gcn slab aggregate launch failed: ") + hipGetErrorString(es));
+    return TRUSS_OK;
+  }
   if ((n_channels & 3) == 0 && n_nodes <= 32 && (((size_t)h | (size_t)out | (size_t)bias) & 15) == 0) {
     // channel-quad threads, no idle lanes
     const int C4 = n_channels / 4;

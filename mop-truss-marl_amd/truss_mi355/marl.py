@@ -111,8 +111,7 @@ def gcn_aggregate(lib, adj, h, bias, act, nbr=None):
         out = torch.empty_like(h)
         ops.call(ops.namespace().gcn_aggregate_sparse, ops.bind(lib), ops.stream_of(h.device), adj, nbr, h, bias, out, code)
         return out
-    if N > 32:     # larger graphs without a pattern: a batched N x N x C GEMM is what rocBLAS is good at (64 nodes x 1024 graphs: 75 us
-                   # against 182 us for the thread-per-channel kernel, tools/agg_probe.py); the channel-quad kernel covers N <= 32
+    if N > 64:     # larger graphs without a pattern: a batched N x N x C GEMM (rocBLAS); the fused dense kernels cover N <= 64
         out = torch.matmul(adj, h) + bias
         return torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
     adj = adj.contiguous()

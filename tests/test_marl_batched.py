@@ -115,6 +115,10 @@ def _check_actor_infer(lib, device):
     bias = r(70)
     for act, f in ((None, lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
         torch.testing.assert_close(marl.gcn_aggregate(lib, adj, h, bias, act), f(torch.matmul(adj, h) + bias), rtol=2e-5, atol=2e-6)
+    for n, c in ((32, 224), (48, 36), (64, 8), (17, 4)):       # 17..64 nodes, channel counts that are multiples of 4: the slab kernel
+        h, adj, bias = r(B, n, c), A(n), r(c)
+        for a_ in (adj, adj[0]):
+            torch.testing.assert_close(marl.gcn_aggregate(lib, a_, h, bias, "relu"), torch.relu(torch.matmul(a_, h) + bias), rtol=2e-5, atol=2e-6)
 
 
 def _check_sparse_aggregate(lib, device):
