@@ -103,6 +103,36 @@ def test_fused_observation_full_size(lib):
         np.testing.assert_allclose(got2[k].cpu().numpy(), ref2[k].cpu().numpy(), rtol=4e-7, atol=1e-7, err_msg=k)
 
 
+def test_fused_observation_soak(lib):
+    """60 chained state-emitting steps at 4096 envs on two copies of the same batch: every step's observation tensors and results are
+    bitwise equal between the copies (the two-wavefront launch -- compute wave + streaming wave over LDS progress words -- is
+    deterministic and leaves no stale byte), finite, and the last step's equal what the stand-alone kernel writes."""
+    topo = synthetic.bench_topology(16, 4)
+    B = 4096
+    batch = synthetic.random_batch(topo, B, 91)
+    ag, at = synthetic.random_actions(4, B, topo.N, 92)
+    e1, e2 = pc.make_env(lib, topo, batch), pc.make_env(lib, topo, batch)
+    assert e1.fused_obs
+    for e in (e1, e2):
+        e.analyze(set_normalisers=True)
+    G = [torch.tensor(a, device=e1.device) for a in ag]
+    T = [torch.tensor(a, device=e1.device) for a in at]
+    o1 = {k: torch.full_like(v, float("nan")) for k, v in e1.obs_buffers().items()}
+    o2 = {k: torch.full_like(v, float("nan")) for k, v in e2.obs_buffers().items()}
+    for s in range(60):
+        e1.step(G[s % 4], T[s % 4], obs=o1)
+        e2.step(G[s % 4], T[s % 4], obs=o2)
+        if s % 10 == 9:
+            for k in o1:
+                assert torch.equal(o1[k], o2[k]), (s, k)
+                assert bool(torch.isfinite(o1[k]).all()), (s, k)
+            assert torch.equal(e1.point, e2.point) and torch.equal(e1.y, e2.y) and torch.equal(e1.sec, e2.sec)
+    ref = e2.observe({k: torch.empty_like(v) for k, v in o2.items()})
+    for k in o1:
+        np.testing.assert_allclose(o1[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=4e-7, atol=1e-7, err_msg=k)
+    assert int(e1.status.sum()) == int(e2.status.sum())
+
+
 def test_full_size_properties(lib):
     """BASELINE size (32 nodes / 80 elements / 4096 envs): size-independent properties.
     (1) a random 256-env sample agrees with the oracle; (2) equilibrium: reactions balance the applied
