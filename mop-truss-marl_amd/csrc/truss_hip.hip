@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void truss_gcn_aggregate_slab_kernel(const flo
 static bool tb_launch_gcn_slab(const float *adj, int64_t a_stride, const int16_t *nbr, int K, const float *h, const float *bias, float *out,
                                int B, int N, int C, int act, hipStream_t st) {
   if ((C & 3) || (((size_t)h | (size_t)out | (size_t)bias) & 15) != 0) return false;   // (out may alias h: a block reads its whole tile first)
-  const int GB = std::max(1, 256 / (8 * N));
+  const int GB = std::max(1, tb_env_int("TRUSS_GCN_SLAB_ITEMS", 512) / (8 * N));   // graphs per block: >= two rounds of items for small graphs
   const size_t lds = (size_t)GB * N * 8 * 16;
   if (lds > 48 * 1024) return false;
   const int C4 = C / 4;
@@ -796,7 +796,7 @@ extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, con
   if (n_batch == 0) return TRUSS_OK;
   // 17..64 nodes: the slab kernel (32 nodes: 58-61 us against 73-84 for the channel-quad kernel below, 64 nodes: 44 against 182 for
   // the thread-per-channel kernel and 75 for rocBLAS + bias + activation); <= 16 nodes: the channel-quad kernel (56 against 74 us)
-  if (n_nodes > 16 && tb_launch_gcn_slab(adj, a_batch_stride, nullptr, n_nodes, h, bias, out, n_batch, n_nodes, n_channels, act, (hipStream_t)stream)) {
+  if (n_nodes > tb_env_int("TRUSS_GCN_SLAB_DENSE_ABOVE", 16) && tb_launch_gcn_slab(adj, a_batch_stride, nullptr, n_nodes, h, bias, out, n_batch, n_nodes, n_channels, act, (hipStream_t)stream)) {
     hipError_t es = hipGetLastError();
     if (es != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("gcn slab aggregate launch failed: ") + hipGetErrorString(es));
     return TRUSS_OK;

@@ -23,7 +23,7 @@ def timed(fn, n=30):
 
 
 out = {}
-for N, B in ((16, 10000), (32, 4096), (48, 2048), (64, 1024), (128, 512), (256, 256)):
+for N, B in ((16, 10000), (20, 9000), (24, 6000), (32, 4096), (48, 2048), (64, 1024), (128, 512), (256, 256)):
     C = 224
     h = torch.rand(B, N, C, device=dev)
     bias = torch.rand(C, device=dev)
@@ -34,6 +34,8 @@ for N, B in ((16, 10000), (32, 4096), (48, 2048), (64, 1024), (128, 512), (256, 
             o = torch.empty_like(h)
             r["fused_us"] = timed(lambda: ops.call(ops.namespace().gcn_aggregate, ops.bind(lib), ops.stream_of(dev), adj.contiguous(), h, bias, o, 1))
         if tag == "shared" or True:
+            if N % 4:
+                r["MB"] = round(2 * h.numel() * 4 / 1e6, 1); out[f"N{N}_B{B}_{tag}"] = r; continue
             topo = tm.TrussTopology.grid(N // 2)
             nbr = torch.tensor(topo.neighbor_table(), device=dev)
             import truss_mi355.ops as ops
