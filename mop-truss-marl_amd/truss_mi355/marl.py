@@ -308,6 +308,15 @@ class BatchedMARL:
         b = S["x_n"].shape[0]
         return [S["x_n"], self.A_n.expand(b, -1, -1), S["A_s"], S["A_n_ts"], S["A_n_cs"], self.mask.expand(b, -1, -1), S["x_p"], S["A_p"]]
 
+    def _noise_vectors(self, noises):
+        """(theta dt, mu, sigma) of a list of OUNoise objects as per-column device vectors (cached on the list's first object)"""
+        hit = getattr(noises[0], "_dev_vectors", None)
+        if hit is None or hit[0].device != self.device:
+            f = lambda vals: torch.tensor(vals, dtype=torch.float32, device=self.device)
+            hit = (f([nz.theta * nz.dt for nz in noises]), f([nz.mu for nz in noises]), f([nz.sigma for nz in noises]))
+            noises[0]._dev_vectors = hit
+        return hit
+
     def _act(self, S, explore):
         ins = self._net_state(S)
         actor_in = [ins[0], ins[1], ins[2], ins[3], ins[4], ins[6], ins[7]]
@@ -316,11 +325,10 @@ class BatchedMARL:
             for ag in self.rl.agents:
                 g, t = actor_infer(self.lib, ag.actor_model, [actor_in[0], self.A_n[0], actor_in[2], actor_in[3], actor_in[4],
                                                               actor_in[5], actor_in[6]], nbr=self.nbr)
-                if explore:                                           # truss2D_RL.OUNoise.gen_noise per scalar (:41-48)
+                if explore:                                           # truss2D_RL.OUNoise.gen_noise per scalar (:41-48), all columns at once
                     for out, noises in ((g, ag.noise_geo), (t, ag.noise_topo)):
-                        for j, nz in enumerate(noises):
-                            out[:, :, j] += nz.theta * (nz.mu - out[:, :, j]) * nz.dt + nz.sigma * torch.randn(
-                                out[:, :, j].shape, device=out.device, generator=self.gen)
+                        th_dt, mu, sg = self._noise_vectors(noises)
+                        out += th_dt * (mu - out) + sg * torch.randn(out.shape, device=out.device, generator=self.gen)
                 geo.append(g.float().contiguous())
                 topo.append(t.float().contiguous())
         return geo, topo
