@@ -20,7 +20,9 @@ for seed in range(s0, s0 + n):
     try:
         info = topo.solver_info(lib)
         kinds[(info["lanes_per_env"], info["half_bandwidth"])] = kinds.get((info["lanes_per_env"], info["half_bandwidth"]), 0) + 1
-        pc.run_random_rollout(lib, 0, 0, 48, 3, seed=seed, topo=topo)
+        # 1e-8: random designs include nearly singular ones (seed 1179, env 37: displacements of 270 m) where an LU (oracle) and an
+        # LDL^T (kernel, emulator alike) differ by cond(K) x 1e-16 ~ 1e-9
+        pc.run_random_rollout(lib, 0, 0, 48, 3, seed=seed, topo=topo, tight=1e-8)
         pc.run_obs_random(lib, 0, 0, 33, seed=seed, fused=True, topo=topo)
     except tm.TrussError as e:
         if "UNSUPPORTED" in str(e).upper() or "unsupported" in str(e):
