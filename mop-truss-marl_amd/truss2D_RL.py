@@ -133,20 +133,76 @@ class multimodes_critic(nn.Module):
         return self.dense_out(q)
 
 
+_seg_cache: dict = {}
+
+
 def _clip_each(params, max_norm=1.0):
     """Keras `clipnorm`: every gradient tensor is clipped to L2 norm <= clipnorm on its own."""
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
     # branch-free (no host synchronisation per tensor): the factor is exactly 1.0 where the norm is within bounds.
-    # Multi-tensor operations throughout: a Python loop over the norms was three tiny launches per parameter tensor,
-    # a third of all launches of an update
-    fac = torch._foreach_add(torch._foreach_norm(grads), 1e-12)
-    torch._foreach_reciprocal_(fac)
+    # A handful of launches whatever the number of tensors: the norms by a multi-tensor kernel, the per-tensor factors as ONE
+    # vector, applied to a flat copy of the gradients through a (cached) element -> tensor index and copied back.  Multiplying a
+    # tensor list by a list of 0-dim factors falls off PyTorch's multi-tensor path: one launch per parameter tensor.
+    fac = torch.stack(torch._foreach_norm(grads)).add_(1e-12).reciprocal_()
     if max_norm != 1.0:
-        torch._foreach_mul_(fac, max_norm)
-    torch._foreach_clamp_max_(fac, 1.0)
-    torch._foreach_mul_(grads, fac)
+        fac.mul_(max_norm)
+    fac.clamp_(max=1.0)
+    key = (tuple(g.numel() for g in grads), grads[0].device)
+    seg = _seg_cache.get(key)
+    if seg is None:
+        seg = torch.repeat_interleave(torch.arange(len(grads), device=grads[0].device),
+                                      torch.tensor([g.numel() for g in grads], device=grads[0].device))
+        _seg_cache[key] = seg
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat.mul_(fac[seg])
+    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+
+class SharedStepAdam:
+    """`torch.optim.Adam(params, lr, betas, eps)` for a parameter list that always steps together (a critic): ONE step counter on the
+    device and multi-tensor launches throughout, usable inside a hipGraph.  PyTorch's capturable Adam keeps a step tensor per
+    parameter, and dividing a tensor list by a list of 0-dim tensors falls off the multi-tensor path: two launches per parameter
+    tensor and step, 96 per critic update.  Same arithmetic: m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2;
+    p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)."""
+
+    def __init__(self, params, lr, eps=1e-8, betas=(0.9, 0.999)):
+        self.params = list(params)
+        self.lr, self.eps, (self.b1, self.b2) = float(lr), float(eps), betas
+        self.step_t, self.exp_avg, self.exp_avg_sq = None, None, None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def state_tensors(self):
+        """the optimiser's state as a flat list (empty before the first step): step counter, first moments, second moments"""
+        return [] if self.step_t is None else [self.step_t] + self.exp_avg + self.exp_avg_sq
+
+    @torch.no_grad()
+    def step(self):
+        ps = self.params
+        if self.step_t is None:
+            self.step_t = torch.zeros((), dtype=torch.float64, device=ps[0].device)   # float64: 1 - 0.999^t cancels badly in float32
+            self.exp_avg = [torch.zeros_like(p) for p in ps]
+            self.exp_avg_sq = [torch.zeros_like(p) for p in ps]
+        grads = [p.grad for p in ps]
+        if any(g is None for g in grads):
+            raise RuntimeError("SharedStepAdam: every parameter must have a gradient (the list steps together)")
+        m, v = self.exp_avg, self.exp_avg_sq
+        self.step_t += 1
+        bc1 = 1 - torch.pow(self.b1, self.step_t)
+        bc2_sqrt = (1 - torch.pow(self.b2, self.step_t)).sqrt_().float()
+        torch._foreach_lerp_(m, grads, 1 - self.b1)
+        torch._foreach_mul_(v, self.b2)
+        torch._foreach_addcmul_(v, grads, grads, value=1 - self.b2)
+        den = torch._foreach_sqrt(v)
+        torch._foreach_div_(den, bc2_sqrt)
+        torch._foreach_add_(den, self.eps)
+        upd = torch._foreach_div(m, den)
+        torch._foreach_mul_(upd, (-self.lr / bc1).float())
+        torch._foreach_add_(ps, upd)
 
 
 def _fresh_adam_step(params, lr, eps):
@@ -301,8 +357,7 @@ class MADDPG:
                     ag.target_critic_model(S + acts)
                 ag.update_init()
             if ag.critic_opt is None:
-                ag.critic_opt = torch.optim.Adam(ag.critic_model.parameters(), lr=ag.lr, eps=1e-7,
-                                                 capturable=self.device.type == "cuda")   # usable inside a hipGraph
+                ag.critic_opt = SharedStepAdam(ag.critic_model.parameters(), lr=ag.lr, eps=1e-7)   # multi-tensor, usable inside a hipGraph
 
     def train(self):
         batch_size = self.batch_size

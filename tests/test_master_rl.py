@@ -235,3 +235,17 @@ def test_update_helpers_match_their_per_tensor_definitions():
     RL._fresh_adam_step(qs, 1e-3, 1e-7)
     for p, q in zip(ps, qs):
         torch.testing.assert_close(q, p, rtol=1e-6, atol=1e-9)
+    # the critic's optimiser: one shared step counter, multi-tensor launches -- six steps against torch.optim.Adam
+    ps, qs = mk(), None
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref, mine = torch.optim.Adam(ps, lr=1e-2, eps=1e-7), RL.SharedStepAdam(qs, lr=1e-2, eps=1e-7)
+    assert mine.state_tensors() == []
+    for it in range(6):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p) * 10.0 ** (it - 3)
+            p.grad, q.grad = g, g.clone()
+        ref.step()
+        mine.step()
+        for p, q in zip(ps, qs):
+            torch.testing.assert_close(q, p, rtol=2e-6, atol=1e-8)
+    assert len(mine.state_tensors()) == 1 + 2 * len(qs) and float(mine.step_t) == 6.0
