@@ -70,16 +70,19 @@ def difference_reward(front_no, n_front_no, pf_hv, n_pf_hv, parent, points, ref_
     f64 = torch.float64
     points = points.to(f64)
     feas = (points <= 1.0).all(dim=2)                                   # _feasible: all four entries <= 1
-    hv_loo = []
-    for i in range(3):                                                  # leave agent i out
-        use = feas.clone()
-        use[:, i] = False
-        pts, n = _append(front_no, n_front_no, points, use)
-        hv_loo.append(front_hv(pts.contiguous(), n, ref_points, max_front, lib)["hv_front"])
-    pts, n = _append(front_no, n_front_no, points, feas)
-    full = front_hv(pts.contiguous(), n, ref_points, max_front, lib)
-    hyperV = full["hv_front"]
-    sum_distance, std_cd = full["metrics"][:, 3], full["metrics"][:, 4]
+    # four point sets per env -- the archive plus the feasible new points with agent 0 / 1 / 2 left out, and with all three --
+    # as ONE batch of 4 B sets: one append pass and one launch instead of four of each
+    B = points.shape[0]
+    use4 = feas[None].repeat(4, 1, 1)                                   # [4, B, 3]
+    for i in range(3):
+        use4[i, :, i] = False                                           # set i: leave agent i out; set 3: everyone
+    rep = lambda t: t[None].expand(4, *t.shape).reshape(4 * B, *t.shape[1:])
+    pts, n = _append(rep(front_no), rep(n_front_no), rep(points), use4.reshape(4 * B, 3))
+    four = front_hv(pts.contiguous(), n, rep(ref_points).contiguous(), max_front, lib)
+    hv4 = four["hv_front"].view(4, B)
+    hv_loo, hyperV = [hv4[0], hv4[1], hv4[2]], hv4[3]
+    metrics = four["metrics"].view(4, B, -1)[3]
+    sum_distance, std_cd = metrics[:, 3], metrics[:, 4]
     compareV = front_hv(pf_hv, n_pf_hv, ref_points, 0, lib)["hv_all"]
     real_compareV = front_hv(pf_hv, n_pf_hv, None, 0, lib)["hv_all"]
     zero = torch.zeros_like(hyperV)
