@@ -4,8 +4,8 @@ a23-a25) for B envs at once.
 `front_hv` is the host mirror of the C entry `truss_front` (include/truss_mi355.h): utils.simple_cull /
 simple_cull_final + utils.union_rectangles_fastest for a batch of small point sets, one wave per env.
 `difference_reward` restates the reward block of master_DDPG_truss2D_MO.run() (:263-368) on top of it:
-six launches (three leave-one-agent-out fronts, the full front, and the archive's own hypervolume with and
-without the reference point) plus a few elementwise float64 torch ops.
+three launches (the three leave-one-agent-out fronts and the full front as one batch of 4 B point sets, and the archive's own
+hypervolume with and without the reference point) plus a few elementwise float64 torch ops.
 
 Deviations from the per-env host path (master_DDPG_truss2D_MO.difference_reward), both documented in the
 header: (1) fronts longer than MAX_FRONT are truncated deterministically, not with random.sample;
