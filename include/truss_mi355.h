@@ -114,6 +114,9 @@ int truss_topo_fused_obs(const truss_topo_t *t);
  * With TRUSS_F_NO_DECODE it is Model.restore(); Model.gen_all() + the objective sums of
  * Game_research04.__init__ (truss2D_ENV.py:264-274) = the reset path (_game_get_1_state :336-340).
  */
+#define TRUSS_STATUS_NOT_SPD 1
+#define TRUSS_STATUS_OBS_TIMEOUT 2
+
 typedef struct truss_step_args {
   size_t struct_size; /* = sizeof(truss_step_args_t), ABI guard */
   int32_t n_envs;     /* B */
@@ -144,14 +147,18 @@ typedef struct truss_step_args {
   float *q0;        /* [B][E]    Element.e_q[0][0] (FEM_2Dtruss.py:383-386) */
   float *sr;        /* [B][E]    Element.prop_yeield (FEM_2Dtruss.py:414-431) */
   uint8_t *comp;    /* [B][E]    Element.iscompress */
-  float *point;     /* [B][4]    [obj1/int_obj1, obj2/int_obj2, con1, con2] (truss2D_ENV.py:518-523) */
+  float *point;     /* [B][4]    [obj1/int_obj1, obj2/int_obj2, con1, con2] (truss2D_ENV.py:518-523); 16-byte aligned (one store per env) */
   float *obj;       /* [B][2] or NULL: raw obj1, obj2 (= int_obj1/2 when called at reset) */
   double *disp_f64; /* [B][N][2] or NULL: float64 copy for solver-level parity checks */
   double *q0_f64;   /* [B][E] or NULL */
   double *energy;   /* [B] or NULL: Model.U_full (FEM_2Dtruss.py:374-379) */
   double *reactions; /* [B][2N-ndof] or NULL: Model.r[ndof:] (FEM_2Dtruss.py:393-411) */
-  int32_t *status;  /* [B] or NULL: 0 ok, 1 = non-positive pivot (K not SPD: the reference would
-                       raise numpy.linalg.LinAlgError from FEM_2Dtruss.py:337 or return garbage) */
+  int32_t *status;  /* [B] or NULL: bit mask, 0 = ok.
+                       TRUSS_STATUS_NOT_SPD (1): non-positive pivot (K not SPD: the reference would raise
+                         numpy.linalg.LinAlgError from FEM_2Dtruss.py:337 or return garbage);
+                       TRUSS_STATUS_OBS_TIMEOUT (2): TRUSS_F_EMIT_OBS only -- the wavefront that streams the observation
+                         tensors gave up waiting for the step's results (bounded wait: the launch always drains); the
+                         observation tensors of this env were NOT (completely) written by this call */
 
   /* observation tensors of the new design, written with TRUSS_F_EMIT_OBS (needs sec_out and max_up_out /
    * max_down_out); same contents and layouts as truss_obs_args_t below; any of them may be NULL */

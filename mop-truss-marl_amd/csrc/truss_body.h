@@ -103,6 +103,8 @@ struct TopoDev {
   int32_t f_area;      // double [n_sections] area in m^2
   int32_t f_isr;       // double [n_sections] 1 / (area * long_stress)
   int32_t f_adj8;      // int16 [N][8]   elements incident to each node, padded with E (a zero slot)
+  int32_t f_exs;       // int16 [E][4]   slots of the element's four end displacements (n0x n0y n1x n1y) in the solution vector;
+                       //                restrained DOFs point at the zero slot (one 8-byte read per element in the post phase)
   int32_t f_areaf;     // float [n_sections] (float)area                          (nN_x_e column 1, ENV:150)
   int32_t f_vsf;       // float [n_sections] (float)(area / largest area)         (A_s, ENV:86-87)
   double e_mod, long_stress;
@@ -134,8 +136,11 @@ struct TopoDev {
   // bytes of the env that are dead by the time they are written (band, solver scratch, action rows)
   int32_t b_const;   // [0] = 0, [1] = 1, [2] = 1 / (1 + 1e-6f)
   // records (LDS stores are the expensive instruction here: two / four 16-byte stores per element / node)
-  int32_t b_erec;    // per element, 8 floats: sec, area, length, tension, compression, violated (nN_x_e columns 0 1 2 3 4 6),
-                     //   A_n_ts value, A_n_cs value (ENV:92-100); + one all-zero record E ("no edge")
+  int32_t b_erec;    // per element, 4 floats: sec, area, length, tension (nN_x_e columns 0 1 2 3)
+  int32_t b_erec2;   // per element, 2 floats: compression, violated (nN_x_e columns 4 6)
+  int32_t b_tc;      // per element, 2 floats: A_n_ts value, A_n_cs value (ENV:92-100); + one all-zero pair E ("no edge").  Written with
+                     //   the member results themselves, so that the first tensors that need the solve start to stream 4 k cycles
+                     //   earlier than the records (progress 2)
   int32_t b_nraw;    // per node, 4 floats: loaded, target / y, |dy|, |dy| / max_def >= 1 (features the step holds in no row)
   int32_t b_nna, b_nnb, b_nn8;   // per node: normalised x_n columns (0 1 4 7), (8 9 10 11) as 4-float records, column 12 as floats
 };
@@ -181,6 +186,7 @@ struct StepLane {
   static constexpr int W = WL * RPL;
   static constexpr int WL_ = WL;
   static constexpr int G_ = G;
+  static constexpr bool EMIT_ = EMIT;
   static constexpr int NPL = (2 * EPL + 4) / 5;   // nodes per lane unrolled (two-row grid trusses: N ~ 0.4 E)
   static constexpr int EPB = 64 / G;  // envs per wave
   static constexpr int NDEG = 8;      // unrolled node-degree bound of the diagonal gather
@@ -233,6 +239,7 @@ struct StepLane {
   TRUSS_HD const double *t_area(const TopoDev &T) const { return TB_TAB(double, TB, T.f_area); }
   TRUSS_HD const double *t_isr(const TopoDev &T) const { return TB_TAB(double, TB, T.f_isr); }
   TRUSS_HD const int16_t *t_adj8(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_adj8); }
+  TRUSS_HD const int16_t *t_exs(const TopoDev &T) const { return TB_TAB(int16_t, TB, T.f_exs); }
 
   // ------------------------------------------------------------------------------------------
   TRUSS_HD void init(int lane_, int block, const TopoDev &T, const StepArgsDev &A, char *lds) {
@@ -441,71 +448,110 @@ struct StepLane {
   }
 
   // ---- phase 1: action decode for the lane's node pairs (all operands in LDS) ----
+  // One vertical pair = one unit of work (the repairs of truss2D_ENV.py:469-490 couple the two nodes).  The first PPL pairs of
+  // a lane are straight-line code: table reads, operand reads, float32 arithmetic with selects (the reference's nested ifs, in
+  // their order), stores -- a pair index past the last pair redoes the arithmetic of pair NP-1 and stores nothing but the
+  // (idempotent) clamped actions.
+  struct PairIn {
+    int n0, n1, f0, f1;
+    float y0, y1, ga0, ga1, gb0, gb1, ta[3], tb[3];
+  };
+  TRUSS_HD void pair_load(const TopoDev &T, int p, PairIn &q) {
+    const float *Y = ysh(T), *GE = geosh(T), *TA = tac(T);
+    const int16_t *PR = t_pairs(T);
+    const uint8_t *NF = t_nflags(T);
+    q.n0 = PR[2 * p];
+    q.n1 = PR[2 * p + 1];
+    q.y0 = Y[q.n0];
+    q.y1 = Y[q.n1];
+    q.f0 = NF[q.n0];
+    q.f1 = NF[q.n1];
+    q.ga0 = GE[2 * q.n0];
+    q.ga1 = GE[2 * q.n0 + 1];
+    q.gb0 = GE[2 * q.n1];
+    q.gb1 = GE[2 * q.n1 + 1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      q.ta[j] = TA[3 * q.n0 + j];
+      q.tb[j] = TA[3 * q.n1 + j];
+    }
+  }
+  TRUSS_HD void pair_decode(const TopoDev &T, const StepArgsDev &A, PairIn &q, bool real) {
+    const size_t bn = (size_t)envc * T.N;
+    float *Y = ysh(T), *TA = tac(T);
+    const int n0 = q.n0, n1 = q.n1;
+    const bool top0 = q.f0 & TF_TOP, top1 = q.f1 & TF_TOP;
+    const float ga0 = tb_clamp01(q.ga0), ga1 = tb_clamp01(q.ga1), gb0 = tb_clamp01(q.gb0), gb1 = tb_clamp01(q.gb1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      q.ta[j] = tb_clamp01(q.ta[j]);
+      q.tb[j] = tb_clamp01(q.tb[j]);
+      TA[3 * n0 + j] = q.ta[j];
+      TA[3 * n1 + j] = q.tb[j];
+    }
+    if ((A.flags & TB_CLAMP_INPLACE) && active && real) {  // truss2D_ENV.py:376-388 mutates the caller's arrays (wave-uniform flag)
+      A.a_geo[(bn + n0) * 2 + 0] = ga0;
+      A.a_geo[(bn + n0) * 2 + 1] = ga1;
+      A.a_geo[(bn + n1) * 2 + 0] = gb0;
+      A.a_geo[(bn + n1) * 2 + 1] = gb1;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        A.a_topo[(bn + n0) * 3 + j] = q.ta[j];
+        A.a_topo[(bn + n1) * 3 + j] = q.tb[j];
+      }
+    }
+    float mu0, md0, mu1, md1;
+    if (A.mu_in) {   // wave-uniform pointer test
+      mu0 = A.mu_in[bn + n0];
+      md0 = A.md_in[bn + n0];
+      mu1 = A.mu_in[bn + n1];
+      md1 = A.md_in[bn + n1];
+    } else {
+      move_range(top0, q.y0, q.y1, mu0, md0);
+      move_range(top1, q.y1, q.y0, mu1, md1);
+    }
+    float a = move_node(q.y0, ga0, ga1, mu0, md0, q.f0 & TF_RESY);
+    float b = move_node(q.y1, gb0, gb1, mu1, md1, q.f1 & TF_RESY);
+    // sequential repairs (truss2D_ENV.py:469-490): visit lo then hi in each of the three loops; every statement sees the values the
+    // previous one left (selects, no branches)
+    // loop 1: below y_min (= 0):   top node -> d_min and its partner to 0; bottom node -> 0
+    const bool c1 = a < 0.0f;
+    a = c1 ? (top0 ? dmin32 : 0.0f) : a;
+    b = (c1 && top0) ? 0.0f : b;
+    const bool c2 = b < 0.0f;
+    b = c2 ? (top1 ? dmin32 : 0.0f) : b;
+    a = (c2 && top1) ? 0.0f : a;
+    // loop 2: above y_max:   top node -> y_max; bottom node -> y_max - d_min and its partner to y_max
+    const bool c3 = a > ymax32;
+    a = c3 ? (top0 ? ymax32 : ymd32) : a;
+    b = (c3 && !top0) ? ymax32 : b;
+    const bool c4 = b > ymax32;
+    b = c4 ? (top1 ? ymax32 : ymd32) : b;
+    a = (c4 && !top1) ? ymax32 : a;
+    // loop 3: pair closer than d_min -> lift the top node
+    a = (top0 && fabsf(a - b) < dmin32) ? b + dmin32 : a;
+    b = (top1 && fabsf(b - a) < dmin32) ? a + dmin32 : b;
+    if (real) {     // in-place update of the heights: a duplicate must not store (clamping the actions twice is idempotent)
+      Y[n0] = a;
+      Y[n1] = b;
+    }
+  }
   TRUSS_HD void phase_decode(const TopoDev &T, const StepArgsDev &A) {
     load_params(T);
     if (A.flags & TB_NO_DECODE) return;
-    const size_t bn = (size_t)envc * T.N;
-    float *Y = ysh(T), *GE = geosh(T), *TA = tac(T);
-    const int16_t *PR = t_pairs(T);
-    const uint8_t *NF = t_nflags(T);
-    for (int p = g; p < T.NP; p += G) {
-      const int n0 = PR[2 * p], n1 = PR[2 * p + 1];
-      const float y0 = Y[n0], y1 = Y[n1];
-      const int f0 = NF[n0], f1 = NF[n1];
-      const bool top0 = f0 & TF_TOP, top1 = f1 & TF_TOP;
-      float ga0 = tb_clamp01(GE[2 * n0]), ga1 = tb_clamp01(GE[2 * n0 + 1]);
-      float gb0 = tb_clamp01(GE[2 * n1]), gb1 = tb_clamp01(GE[2 * n1 + 1]);
-      float ta[3], tb[3];
+    constexpr int PPL = (NPL + 1) / 2;
+    PairIn q[PPL];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        ta[j] = tb_clamp01(TA[3 * n0 + j]);
-        tb[j] = tb_clamp01(TA[3 * n1 + j]);
-        TA[3 * n0 + j] = ta[j];
-        TA[3 * n1 + j] = tb[j];
-      }
-      if ((A.flags & TB_CLAMP_INPLACE) && active) {  // truss2D_ENV.py:376-388 mutates the caller's arrays
-        A.a_geo[(bn + n0) * 2 + 0] = ga0;
-        A.a_geo[(bn + n0) * 2 + 1] = ga1;
-        A.a_geo[(bn + n1) * 2 + 0] = gb0;
-        A.a_geo[(bn + n1) * 2 + 1] = gb1;
+    for (int i = 0; i < PPL; ++i) {
+      const int p = g + G * i;
+      pair_load(T, p < T.NP ? p : T.NP - 1, q[i]);
+    }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          A.a_topo[(bn + n0) * 3 + j] = ta[j];
-          A.a_topo[(bn + n1) * 3 + j] = tb[j];
-        }
-      }
-      float mu0, md0, mu1, md1;
-      if (A.mu_in) {
-        mu0 = A.mu_in[bn + n0];
-        md0 = A.md_in[bn + n0];
-        mu1 = A.mu_in[bn + n1];
-        md1 = A.md_in[bn + n1];
-      } else {
-        move_range(top0, y0, y1, mu0, md0);
-        move_range(top1, y1, y0, mu1, md1);
-      }
-      float a = move_node(y0, ga0, ga1, mu0, md0, f0 & TF_RESY);
-      float b = move_node(y1, gb0, gb1, mu1, md1, f1 & TF_RESY);
-      // sequential repairs (truss2D_ENV.py:469-490): visit lo then hi in each of the three loops
-      // loop 1: below y_min (= 0)
-      if (a < 0.0f) {
-        if (top0) { a = dmin32; b = 0.0f; } else { a = 0.0f; }
-      }
-      if (b < 0.0f) {
-        if (top1) { b = dmin32; a = 0.0f; } else { b = 0.0f; }
-      }
-      // loop 2: above y_max
-      if (a > ymax32) {
-        if (top0) { a = ymax32; } else { a = ymd32; b = ymax32; }
-      }
-      if (b > ymax32) {
-        if (top1) { b = ymax32; } else { b = ymd32; a = ymax32; }
-      }
-      // loop 3: pair closer than d_min -> lift the top node
-      if (top0 && fabsf(a - b) < dmin32) a = b + dmin32;
-      if (top1 && fabsf(b - a) < dmin32) b = a + dmin32;
-      Y[n0] = a;
-      Y[n1] = b;
+    for (int i = 0; i < PPL; ++i) pair_decode(T, A, q[i], g + G * i < T.NP);
+    for (int p = g + G * PPL; p < T.NP; p += G) {     // topologies with more pairs per lane than the unrolled part covers
+      PairIn r;
+      pair_load(T, p, r);
+      pair_decode(T, A, r, true);
     }
   }
 
@@ -522,27 +568,47 @@ struct StepLane {
   }
 
   // ---- phase 3: section update (truss2D_ENV.py:421-466), in place in LDS ----
+  // Straight-line: connectivity + current sections of the lane's EPL elements, then the six action values of each, then the
+  // argmax / +-1 / clamp, then the (guarded) stores: the loads of all elements are in flight together.
   TRUSS_HD void phase_sizing(const TopoDev &T, const StepArgsDev &A) {
     if (A.flags & TB_NO_DECODE) return;
     const float *TA = tac(T);
     int32_t *S = secsh(T);
     const int16_t *CN = t_conn(T);
+    int n0[EPL], n1[EPL], sc[EPL];
+    float a0[EPL][3], a1[EPL][3];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
       const int e = g + G * i;
       const int ee = e < T.E ? e : T.E - 1;
-      const int n0 = CN[2 * ee], n1 = CN[2 * ee + 1];
-      int s = S[ee];
-      float p0 = TA[n0 * 3 + 0] + TA[n1 * 3 + 0];
-      float p1 = TA[n0 * 3 + 1] + TA[n1 * 3 + 1];
-      float p2 = TA[n0 * 3 + 2] + TA[n1 * 3 + 2];
+      const uint32_t c = *(const uint32_t *)(CN + 2 * ee);    // both end nodes: one 4-byte read
+      n0[i] = (int)(int16_t)(c & 0xffffu);
+      n1[i] = (int)(int16_t)(c >> 16);
+      sc[i] = S[ee];
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        a0[i][j] = TA[n0[i] * 3 + j];
+        a1[i][j] = TA[n1[i] * 3 + j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const float p0 = a0[i][0] + a1[i][0], p1 = a0[i][1] + a1[i][1], p2 = a0[i][2] + a1[i][2];
       int am = 0;
       float best = p0;
       if (p1 > best) { am = 1; best = p1; }
       if (p2 > best) { am = 2; }
-      int sdn = s > 0 ? s - 1 : 0, sup = s < T.n_sections - 1 ? s + 1 : T.n_sections - 1;
-      s = am == 0 ? sdn : (am == 1 ? sup : s);
-      if (e < T.E) S[e] = s;
+      const int s = sc[i];
+      const int sdn = s > 0 ? s - 1 : 0, sup = s < T.n_sections - 1 ? s + 1 : T.n_sections - 1;
+      sc[i] = am == 0 ? sdn : (am == 1 ? sup : s);
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const int e = g + G * i;
+      if (e < T.E) S[e] = sc[i];     // in-place update: a duplicate must not store (it would be harmless in lock-step only)
     }
   }
 
@@ -641,28 +707,65 @@ struct StepLane {
     const double *EV = evsh(T);
     const int16_t *AD = t_adj8(T), *DO = t_diagoff(T);
     double *K = kb(T);
-    auto node = [&](int n) {
-      double cc = 0.0, cs = 0.0, ss = 0.0;
+    // the first NPL nodes of a lane, straight-line: the adjacency rows (one 16-byte read per node) and the band offsets of all of
+    // them, then the incident elements' values in two rounds of four per node -- the loads of a round are in flight together, the
+    // sums keep the ascending element order --, then the stores.  (With one node after the other the loads of the second node
+    // could not pass the band stores of the first: K and the element values are both LDS doubles to the compiler.)  A node index
+    // past the last node redoes node N-1 (same values to the same places).
+    static_assert(NDEG == 8, "adjacency rows are read as one 16-byte unit");
+    tb_u4 adj[NPL];
+    int dof[NPL][3];
+    double cc[NPL], cs[NPL], ss[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n0 = g + G * i, n = n0 < T.N ? n0 : T.N - 1;
+      adj[i] = *(const tb_u4 *)(AD + n * NDEG);
+      dof[i][0] = DO[3 * n];
+      dof[i][1] = DO[3 * n + 1];
+      dof[i][2] = DO[3 * n + 2];
+      cc[i] = cs[i] = ss[i] = 0.0;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double ev[NPL][4][3];
+#pragma unroll
+      for (int i = 0; i < NPL; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const uint32_t w = adj[i][2 * h + (a >> 1)];
+          const int e = (a & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+          ev[i][a][0] = EV[3 * e + 0];
+          ev[i][a][1] = EV[3 * e + 1];
+          ev[i][a][2] = EV[3 * e + 2];
+        }
+#pragma unroll
+      for (int i = 0; i < NPL; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          cc[i] += ev[i][a][0];
+          cs[i] += ev[i][a][1];
+          ss[i] += ev[i][a][2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      K[dof[i][0]] = cc[i];      // restrained DOFs point at the trash slot
+      K[dof[i][1]] = ss[i];
+      K[dof[i][2]] = cs[i];
+    }
+    for (int n = g + G * NPL; n < T.N; n += G) {     // topologies with more nodes per lane than the unrolled part covers
+      double c2 = 0.0, s2 = 0.0, x2 = 0.0;
 #pragma unroll
       for (int a = 0; a < NDEG; ++a) {
         const int e = AD[n * NDEG + a];
-        cc += EV[3 * e + 0];
-        cs += EV[3 * e + 1];
-        ss += EV[3 * e + 2];
+        c2 += EV[3 * e + 0];
+        x2 += EV[3 * e + 1];
+        s2 += EV[3 * e + 2];
       }
-      K[DO[3 * n]] = cc;      // restrained DOFs point at the trash slot
-      K[DO[3 * n + 1]] = ss;
-      K[DO[3 * n + 2]] = cs;
-    };
-    // the first NPL nodes of a lane are unrolled with clamped indices (a duplicate recomputes and rewrites the
-    // same values): the two levels of dependent LDS gathers of different nodes overlap instead of queueing
-    // behind a loop with a run-time trip count; topologies with more nodes per lane take the plain loop
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int n = g + G * i;
-      node(n < T.N ? n : T.N - 1);
+      K[DO[3 * n]] = c2;
+      K[DO[3 * n + 1]] = s2;
+      K[DO[3 * n + 2]] = x2;
     }
-    for (int n = g + G * NPL; n < T.N; n += G) node(n);
     // identity rows: team A beyond its part + middle; team B beyond the middle (its middle rows keep a
     // zero diagonal: they are never pivots of team B)
     const int idA = T.nteams == 1 ? T.ndof : T.ndof - T.KA;
@@ -944,36 +1047,84 @@ struct StepLane {
   TRUSS_HD uint8_t *ocomp(const TopoDev &T) { return (uint8_t *)(L + T.o_kb + T.so_comp); }
 
   // ---- phase 6: member forces, stress ratios, reactions (FEM_2Dtruss.py:341-431) ----
+  // Straight-line over the lane's EPL elements: every table read first, then every solution read, then the arithmetic, then the
+  // stores -- the three levels of dependent LDS reads of different elements overlap (a loop body with guards ran them one
+  // element after the other: 7 k of a workgroup's 43 k cycles).  An index past the last element redoes element E-1 (same
+  // values to the same places; max is idempotent).  The optional float64 / reaction outputs run behind, under wave-uniform
+  // guards, from the values kept in registers.
   TRUSS_HD void phase_post_elements(const TopoDev &T, const StepArgsDev &A) {
     const double *XS = xsol(T);
-    const int16_t *CN = t_conn(T), *DP = t_dofpos(T), *RS = t_restslot(T);
-    const size_t be = (size_t)envc * T.E;
-    const int zslot = T.zslot;
+    const int16_t *EX = t_exs(T);
     float *Q = oq0(T), *SR = osr(T);
     uint8_t *CP = ocomp(T);
+    tb_u2 ex[EPL];
+    double qv[EPL];
+    float srv[EPL];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
       const int e = g + G * i;
       const int ee = e < T.E ? e : T.E - 1;
-      const int n0 = CN[2 * ee], n1 = CN[2 * ee + 1];
-      const int p0 = DP[2 * n0], p1 = DP[2 * n0 + 1], p2 = DP[2 * n1], p3 = DP[2 * n1 + 1];
-      const double v0 = XS[p0 < 0 ? zslot : p0], v1 = XS[p1 < 0 ? zslot : p1];
-      const double v2 = XS[p2 < 0 ? zslot : p2], v3 = XS[p3 < 0 ? zslot : p3];
+      ex[i] = *(const tb_u2 *)(EX + 4 * ee);
+    }
+    double v[EPL][4];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      v[i][0] = XS[ex[i][0] & 0xffffu];
+      v[i][1] = XS[ex[i][0] >> 16];
+      v[i][2] = XS[ex[i][1] & 0xffffu];
+      v[i][3] = XS[ex[i][1] >> 16];
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
       const double c = ec[i], s = es[i], k = ek[i];
-      const double u0 = c * v0 + s * v1;
-      const double u2 = c * v2 + s * v3;
+      const double u0 = c * v[i][0] + s * v[i][1];
+      const double u2 = c * v[i][2] + s * v[i][3];
       const double q = k * u0 + (-k) * u2;
-      const float srf = (float)(fabs(q) * ei[i]);  // |q/A| / long_stress (FEM:419,429)
-      if (e < T.E) {
-        p_c1 = fmaxf(p_c1, fabsf(srf));
-        Q[e] = (float)q;
-        SR[e] = srf;
-        CP[e] = q > 0.0 ? 1 : 0;
-        if (A.q064 && active) A.q064[be + e] = q;
-        if (A.react) {
-          // f = T^T q = q0 * [c, s, -c, -s] summed into the restrained DOFs (FEM:389-411)
-          int s0 = RS[2 * n0], s1 = RS[2 * n0 + 1];
-          int s2 = RS[2 * n1], s3 = RS[2 * n1 + 1];
+      qv[i] = q;
+      srv[i] = (float)(fabs(q) * ei[i]);  // |q/A| / long_stress (FEM:419,429)
+      p_c1 = fmaxf(p_c1, fabsf(srv[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const int e = g + G * i;
+      const int ee = e < T.E ? e : T.E - 1;
+      Q[ee] = (float)qv[i];
+      SR[ee] = srv[i];
+      CP[ee] = qv[i] > 0.0 ? 1 : 0;
+      if constexpr (EMIT) {   // the two edge values of A_n_ts / A_n_cs (ENV:92-100): all that the first post-solve tensors need
+        const bool cmp = qv[i] > 0.0;
+        const float val = fminf(srv[i], 1.0f) * (srv[i] > 1.0f ? 1.0f : 0.5f);
+        const tb_f2 tc = {cmp ? 0.0f : val, cmp ? val : 0.0f};
+        ((tb_f2 *)((float *)L + T.b_tc))[ee] = tc;
+        pe_sr[i] = srv[i];
+        pe_cmp = i == 0 ? (cmp ? 1u : 0u) : (pe_cmp | (cmp ? 1u << i : 0u));
+      }
+    }
+    if constexpr (EMIT) {
+      if (g == 0) {
+        const tb_f2 z = {0.0f, 0.0f};
+        ((tb_f2 *)((float *)L + T.b_tc))[T.E] = z;                      // "no edge"
+      }
+    }
+    if (A.q064 && active) {      // wave-uniform pointer test
+      const size_t be = (size_t)envc * T.E;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        const int e = g + G * i;
+        if (e < T.E) A.q064[be + e] = qv[i];
+      }
+    }
+    if (A.react) {
+      // f = T^T q = q0 * [c, s, -c, -s] summed into the restrained DOFs (FEM:389-411)
+      const int16_t *CN = t_conn(T), *RS = t_restslot(T);
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        const int e = g + G * i;
+        if (e < T.E) {
+          const int n0 = CN[2 * e], n1 = CN[2 * e + 1];
+          const double q = qv[i], c = ec[i], s = es[i];
+          const int s0 = RS[2 * n0], s1 = RS[2 * n0 + 1];
+          const int s2 = RS[2 * n1], s3 = RS[2 * n1 + 1];
           if (s0 >= 0) tb_lds_add(&rbuf(T)[s0], q * c);
           if (s1 >= 0) tb_lds_add(&rbuf(T)[s1], q * s);
           if (s2 >= 0) tb_lds_add(&rbuf(T)[s2], q * (-c));
@@ -984,6 +1135,7 @@ struct StepLane {
   }
 
   // ---- phase 7: nodal results, move ranges of the new design, objective partials ----
+  // Straight-line like phase 6: table reads, solution reads, arithmetic with selects instead of branches, stores.
   TRUSS_HD void phase_post_nodes(const TopoDev &T, const StepArgsDev &A) {
     const double *XS = xsol(T);
     const float *Y = ysh(T), *TG = tgsh(T);
@@ -992,31 +1144,73 @@ struct StepLane {
     const size_t bn = (size_t)envc * T.N;
     const int zslot = T.zslot;
     float *DS = odisp(T), *MU = omu(T), *MD = omd(T);
-    auto node = [&](int n, bool real) {   // real = false: a clamped duplicate of node N-1 (loads and stores only)
-      int px = DP[2 * n], py = DP[2 * n + 1];
-      double dx = XS[px < 0 ? zslot : px], dy = XS[py < 0 ? zslot : py];
-      bool top = NF[n] & TF_TOP;
-      float y = Y[n];
-      if (top) {
-        p_dt += real ? (double)fabsf(TG[n] - y) : 0.0;  // all_dt (ENV:514)
-      } else {
-        p_c2 = real ? fmaxf(p_c2, fabsf((float)(dy / max_def))) : p_c2;  // all_d (ENV:516)
+    int px[NPL], py[NPL], fl[NPL];
+    float yv[NPL], tg[NPL];
+    double dxv[NPL], dyv[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {       // a clamped duplicate of node N-1 recomputes and rewrites the same values
+      const int n0 = g + G * i, n = n0 < T.N ? n0 : T.N - 1;
+      px[i] = DP[2 * n];
+      py[i] = DP[2 * n + 1];
+      fl[i] = NF[n];
+      yv[i] = Y[n];
+      tg[i] = TG[n];
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      dxv[i] = XS[px[i] < 0 ? zslot : px[i]];
+      dyv[i] = XS[py[i] < 0 ? zslot : py[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n0 = g + G * i, n = n0 < T.N ? n0 : T.N - 1;
+      const bool real = n0 < T.N, top = fl[i] & TF_TOP;
+      const double dt = (double)fabsf(tg[i] - yv[i]);                 // all_dt (ENV:514)
+      const float dr = fabsf((float)(dyv[i] / max_def));             // all_d (ENV:516)
+      p_dt += (real && top) ? dt : 0.0;
+      p_c2 = top ? p_c2 : fmaxf(p_c2, dr);                            // (a duplicate repeats node N-1's value: max is idempotent)
+      DS[2 * n + 0] = (float)dxv[i];
+      DS[2 * n + 1] = (float)dyv[i];
+    }
+    if (A.disp64 && active) {      // wave-uniform pointer test
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = g + G * i;
+        if (n < T.N) {
+          A.disp64[(bn + n) * 2 + 0] = dxv[i];
+          A.disp64[(bn + n) * 2 + 1] = dyv[i];
+        }
       }
+    }
+    for (int n = g + G * NPL; n < T.N; n += G) {     // topologies with more nodes per lane than the unrolled part covers
+      const int qx = DP[2 * n], qy = DP[2 * n + 1];
+      const double dx = XS[qx < 0 ? zslot : qx], dy = XS[qy < 0 ? zslot : qy];
+      const float y = Y[n];
+      if (NF[n] & TF_TOP) p_dt += (double)fabsf(TG[n] - y);
+      else p_c2 = fmaxf(p_c2, fabsf((float)(dy / max_def)));
       DS[2 * n + 0] = (float)dx;
       DS[2 * n + 1] = (float)dy;
-      if (A.disp64 && active && real) {
+      if (A.disp64 && active) {
         A.disp64[(bn + n) * 2 + 0] = dx;
         A.disp64[(bn + n) * 2 + 1] = dy;
       }
-    };
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {       // unrolled like phase_assemble_nodes: the gathers of the lane's nodes overlap
-      const int n = g + G * i;
-      node(n < T.N ? n : T.N - 1, n < T.N);
     }
-    for (int n = g + G * NPL; n < T.N; n += G) node(n, true);
     if (A.mu_out && T.has_pairs) {
-      for (int p = g; p < T.NP; p += G) {
+      constexpr int PPL = (NPL + 1) / 2;
+#pragma unroll
+      for (int i = 0; i < PPL; ++i) {
+        const int p0 = g + G * i, p = p0 < T.NP ? p0 : T.NP - 1;
+        const int lo = PR[2 * p], hi = PR[2 * p + 1];
+        const float ylo = Y[lo], yhi = Y[hi];
+        float u0, d0, u1, d1;
+        move_range(NF[lo] & TF_TOP, ylo, yhi, u0, d0);
+        move_range(NF[hi] & TF_TOP, yhi, ylo, u1, d1);
+        MU[lo] = u0;
+        MD[lo] = d0;
+        MU[hi] = u1;
+        MD[hi] = d1;
+      }
+      for (int p = g + G * PPL; p < T.NP; p += G) {
         int lo = PR[2 * p], hi = PR[2 * p + 1];
         move_range(NF[lo] & TF_TOP, Y[lo], Y[hi], MU[lo], MD[lo]);
         move_range(NF[hi] & TF_TOP, Y[hi], Y[lo], MU[hi], MD[hi]);
@@ -1024,13 +1218,6 @@ struct StepLane {
     }
     if (A.energy)
       for (int r = g; r < T.ndof; r += G) p_en += XS[r] * load_at(T, r);
-    double *RD = red(T);
-    RD[0 * G + g] = p_vol;
-    RD[1 * G + g] = p_dt;
-    RD[2 * G + g] = (double)p_c1;
-    RD[3 * G + g] = (double)p_c2;
-    RD[4 * G + g] = p_en;
-    RD[5 * G + g] = (double)bad;
   }
 
   // copy one result row LDS -> HBM with the env's own G lanes (generic fallback)
@@ -1111,43 +1298,35 @@ struct StepLane {
     }
   }
 
-  // ---- phase 8: six lanes per env each fold ONE quantity (fixed order) and write their share ----
-  //   lane 0: obj1 -> point[0], obj[0]   lane 1: obj2 -> point[1], obj[1]   lane 2: con1 -> point[2]
-  //   lane 3: con2 -> point[3]           lane 4: energy, reactions          lane 5: status
+  // ---- phase 8: the env's objective partials are folded across its G lanes in registers (DPP butterfly: tb_group_sum_d /
+  // tb_group_max_f; the float32 contributions are summed in float64, which is exact, so the order does not matter) and a few
+  // lanes write the results:  lane 0: point (one 16-byte store), obj   lane 1: energy, reactions   lane 2: status
+  // (Through LDS -- every lane's partials stored, six lanes folding 16 values each -- this phase took 2.2 k of 43 k cycles.)
   TRUSS_HD void phase_finish(const TopoDev &T, const StepArgsDev &A) {
+    const double s_vol = tb_group_sum_d(*this, 0), s_dt = tb_group_sum_d(*this, 1);
+    const float m_c1 = tb_group_max_f(*this, 0), m_c2 = tb_group_max_f(*this, 1), m_bad = tb_group_max_f(*this, 2);
+    double s_en = 0.0;
+    if (A.energy) s_en = tb_group_sum_d(*this, 2);     // wave-uniform
     if (!active) return;
-    for (int q = g; q < 6; q += G) finish_one(T, A, q);
-  }
-  TRUSS_HD void finish_one(const TopoDev &T, const StepArgsDev &A, int q) {
-    const double *RD = red(T) + q * G;
-    double sum = 0.0, mx = 0.0;
-    for (int j = 0; j < G; ++j) {
-      const double v = RD[j];
-      sum += v;
-      mx = v > mx ? v : mx;
+    if (g == 0) {
+      const float obj1 = (float)s_vol, obj2 = (float)s_dt;
+      const tb_f4 pt = {obj1 / int1, obj2 / int2, m_c1, m_c2};
+      *(tb_f4 *)(A.point + (size_t)env * 4) = pt;
+      if (A.obj) {
+        const tb_f2 o = {obj1, obj2};
+        *(tb_f2 *)(A.obj + (size_t)env * 2) = o;
+      }
     }
-    float *pt = A.point + (size_t)env * 4;
-    if (q == 0) {
-      const float obj1 = (float)sum;
-      pt[0] = obj1 / int1;
-      if (A.obj) A.obj[(size_t)env * 2 + 0] = obj1;
-    } else if (q == 1) {
-      const float obj2 = (float)sum;
-      pt[1] = obj2 / int2;
-      if (A.obj) A.obj[(size_t)env * 2 + 1] = obj2;
-    } else if (q == 2) {
-      pt[2] = (float)mx;
-    } else if (q == 3) {
-      pt[3] = (float)mx;
-    } else if (q == 4) {
-      if (A.energy) A.energy[env] = 0.5 * sum;
+    if (g == 1 % G) {
+      if (A.energy) A.energy[env] = 0.5 * s_en;
       if (A.react) {
         const double *RB = rbuf(T);
         for (int i = 0; i < T.n_rest; ++i) A.react[(size_t)env * T.n_rest + i] = RB[i];
       }
-    } else {
-      if (A.status) A.status[env] = sum != 0.0 ? 1 : 0;
     }
+    // bit 0: non-positive pivot; bit 1: the streaming wave of an EMIT workgroup gave up waiting (tb_obs_timed_out: the workgroup's
+    // timeout word; the streaming wave also raises the bit itself, in case this wave is the one that never gets here)
+    if (g == 2 % G && A.status) A.status[env] = (m_bad != 0.0f ? 1 : 0) | (tb_obs_timed_out(*this, T) ? 2 : 0);
   }
 
   // ==== observation emission (EMIT) ==============================================================
@@ -1248,7 +1427,7 @@ struct StepLane {
             if (b0 + k < IM) {
               const tb_f4 v = {sc[k][0] >= 0 ? VF[sc[k][0]] : 0.0f, sc[k][1] >= 0 ? VF[sc[k][1]] : 0.0f,
                                sc[k][2] >= 0 ? VF[sc[k][2]] : 0.0f, sc[k][3] >= 0 ? VF[sc[k][3]] : 0.0f};
-              TB_STREAM_STORE(&o4[chunk_of(b0 + k, T.nc_mat)], v);
+              TB_OBS_STORE(&o4[chunk_of(b0 + k, T.nc_mat)], v);
             }
         }
       }
@@ -1258,7 +1437,7 @@ struct StepLane {
   TRUSS_HD void obs_emit_tc(const TopoDev &T, const StepArgsDev &A) {
     if constexpr (EMIT) {
       if (!active || (!A.A_ts && !A.A_cs)) return;
-      const tb_f2 *R = (const tb_f2 *)((const float *)L + T.b_erec) + 3;   // (A_n_ts, A_n_cs) = floats 6, 7 of an 8-float record
+      const tb_f2 *R = (const tb_f2 *)((const float *)L + T.b_tc);
       const size_t nn4 = (size_t)T.N * T.N / 4;
       tb_f4 *pt = (tb_f4 *)A.A_ts + env * nn4, *pc = (tb_f4 *)A.A_cs + env * nn4;
 #pragma unroll
@@ -1269,10 +1448,10 @@ struct StepLane {
           for (int k = 0; k < KB; ++k)
             if (b0 + k < IM) {
               const tb_u2 t = etm[b0 + k];
-              r[k][0] = R[4 * (t[0] & 0xffffu)];
-              r[k][1] = R[4 * (t[0] >> 16)];
-              r[k][2] = R[4 * (t[1] & 0xffffu)];
-              r[k][3] = R[4 * (t[1] >> 16)];
+              r[k][0] = R[t[0] & 0xffffu];
+              r[k][1] = R[t[0] >> 16];
+              r[k][2] = R[t[1] & 0xffffu];
+              r[k][3] = R[t[1] >> 16];
             }
 #pragma unroll
           for (int k = 0; k < KB; ++k)
@@ -1280,40 +1459,39 @@ struct StepLane {
               const int q = chunk_of(b0 + k, T.nc_mat);
               const tb_f4 vt = {r[k][0][0], r[k][1][0], r[k][2][0], r[k][3][0]};
               const tb_f4 vc = {r[k][0][1], r[k][1][1], r[k][2][1], r[k][3][1]};
-              if (A.A_ts) TB_STREAM_STORE(&pt[q], vt);
-              if (A.A_cs) TB_STREAM_STORE(&pc[q], vc);
+              if (A.A_ts) TB_OBS_STORE(&pt[q], vt);
+              if (A.A_cs) TB_OBS_STORE(&pc[q], vc);
             }
         }
       }
     }
   }
 
-  // ---- bank, elements (compute wave, behind post_elements): nN_x_e columns 0-4, 6 (ENV:148-156) and the edge values of
-  // A_n_ts / A_n_cs (ENV:92-100) from the rows the step staged
+  // ---- bank, elements (compute wave, behind progress 2): nN_x_e columns 0-4, 6 (ENV:148-156) from the registers of post_elements
+  float pe_sr[EMIT ? EPL : 1];
+  uint32_t pe_cmp;               // bit i: element i of the lane is in compression
   TRUSS_HD void obs_elements_bank(const TopoDev &T, const StepArgsDev &A) {
     if constexpr (EMIT) {
       float *Lf = (float *)L;
-      const float *SR = osr(T);
       const int32_t *S = secsh(T);
-      const uint8_t *CP = ocomp(T);
       const float *AF = TB_TAB(float, TB, T.f_areaf);
+      int sc[EPL];
 #pragma unroll
       for (int i = 0; i < EPL; ++i) {
         const int e = g + G * i;
-        const int ee = e < T.E ? e : T.E - 1;   // a clamped duplicate rewrites element E-1's values
-        const int sc = S[ee];
-        const float srv = SR[ee];
-        const bool cmp = CP[ee] != 0;
-        const float val = fminf(srv, 1.0f) * (srv > 1.0f ? 1.0f : 0.5f);
-        const tb_f4 r0 = {(float)sc, AF[sc], el[i], cmp ? 0.0f : 1.0f};
-        const tb_f4 r1 = {cmp ? 1.0f : 0.0f, srv > 1.0f ? 1.0f : 0.0f, cmp ? 0.0f : val, cmp ? val : 0.0f};
-        tb_f4 *rec = (tb_f4 *)(Lf + T.b_erec) + 2 * ee;
-        rec[0] = r0;
-        rec[1] = r1;
+        sc[i] = S[e < T.E ? e : T.E - 1];      // a clamped duplicate rewrites element E-1's values
+      }
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        const int e = g + G * i;
+        const int ee = e < T.E ? e : T.E - 1;
+        const bool cmp = (pe_cmp >> i) & 1u;
+        const tb_f4 r0 = {(float)sc[i], AF[sc[i]], el[i], cmp ? 0.0f : 1.0f};
+        const tb_f2 r1 = {cmp ? 1.0f : 0.0f, pe_sr[i] > 1.0f ? 1.0f : 0.0f};
+        ((tb_f4 *)(Lf + T.b_erec))[ee] = r0;
+        ((tb_f2 *)(Lf + T.b_erec2))[ee] = r1;
       }
       if (g == 0) {
-        const tb_f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        ((tb_f4 *)(Lf + T.b_erec))[2 * T.E + 1] = z;                    // the "no edge" record (its A_n_ts / A_n_cs half)
         Lf[T.b_const + 0] = 0.0f;
         Lf[T.b_const + 1] = 1.0f;
         Lf[T.b_const + 2] = (1.0f - 0.0f) / (1.0f - 0.0f + 1e-6f);   // a 0/1 column with both values present
@@ -1411,7 +1589,7 @@ struct StepLane {
           if (b0 + k < IT) v[k] = gather4(Lf, tab[b0 + k]);
 #pragma unroll
         for (int k = 0; k < KB; ++k)
-          if (b0 + k < IT) TB_STREAM_STORE(&o4[chunk_of(b0 + k, nc)], v[k]);
+          if (b0 + k < IT) TB_OBS_STORE(&o4[chunk_of(b0 + k, nc)], v[k]);
       }
     }
   }
@@ -1444,7 +1622,7 @@ struct StepLane {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int q = q0 + k * G < nc ? q0 + k * G : nc - 1;
-          TB_STREAM_STORE((tb_f2 *)o + q, v[k]);
+          TB_OBS_STORE((tb_f2 *)o + q, v[k]);
         }
       }
     } else {
@@ -1453,7 +1631,7 @@ struct StepLane {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = Lf[tab[q0 + k * G < nc ? q0 + k * G : nc - 1]];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) TB_STREAM_STORE(o + (q0 + k * G < nc ? q0 + k * G : nc - 1), v[k]);
+        for (int k = 0; k < 4; ++k) TB_OBS_STORE(o + (q0 + k * G < nc ? q0 + k * G : nc - 1), v[k]);
       }
     }
   }
@@ -1645,9 +1823,9 @@ struct StepLane {
   PH_NS(rollout_stash(T, A));                                                       \
   PH(phase_post_elements(T, A));                                                    \
   if (EMIT_) {                                                                      \
-    PH(obs_elements_bank(T, A));                                                    \
     EMIT_POINT(2);                                                                  \
     TRUSS_ST(18);                                                                   \
+    PH(obs_elements_bank(T, A));                                                    \
   }                                                                                 \
   TRUSS_ST(7);                                                                      \
   PH(phase_post_nodes(T, A));                                                       \

@@ -22,6 +22,12 @@
 // result rows are written once and not read again by this launch: streaming (non-temporal) stores leave
 // no dirty lines behind for the end-of-kernel write-back
 #define TB_STREAM_STORE(p, v) __builtin_nontemporal_store((v), (p))
+// observation tensors of the fused step (~100 MB per 4096-env launch, re-written every step): see DESIGN.md section 4.1b / tools/write_probe.hip
+#ifdef TRUSS_OBS_STORE_NT
+#define TB_OBS_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define TB_OBS_STORE(p, v) (*(p) = (v))
+#endif
 
 // LDS float64 scatter-add (ds_add_f64 on gfx950)
 __device__ __forceinline__ void tb_lds_add(double *p, double v) { unsafeAtomicAdd(p, v); }
@@ -84,7 +90,7 @@ __device__ __forceinline__ float tb_rcpf(float d) {
 __device__ unsigned long long g_truss_stamps[32];
 // g_truss_span: every workgroup's first and last stamp as (shader clock, 100 MHz wall clock): spread of
 // the workgroups over the launch, effective shader frequency (tools/span.py).
-__device__ unsigned long long g_truss_span[4096][4];
+__device__ unsigned long long g_truss_span[4096][6];   // [4], [5]: the streaming wave's start / end wall clock (EMIT)
 #define TRUSS_ST(i)                                                  \
   do {                                                               \
     __builtin_amdgcn_sched_barrier(0);                               \
@@ -127,29 +133,74 @@ __device__ __forceinline__ float tb_group_min(LN &ln, int c) { return tb_group_r
 template <class LN>
 __device__ __forceinline__ float tb_group_max(LN &ln, int c) { return tb_group_reduce<LN::G_, true>(ln.pmx[c]); }
 
+// sum of a double over the G lanes of an env (all lanes get the result): the same butterfly as tb_group_reduce
+template <int G>
+__device__ __forceinline__ double tb_group_reduce_sum(double v) {
+  auto dpp = [](double x, auto ctrl) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  if constexpr (G >= 2) v = v + dpp(v, std::integral_constant<int, 0xB1>{});
+  if constexpr (G >= 4) v = v + dpp(v, std::integral_constant<int, 0x4E>{});
+  if constexpr (G >= 8) v = v + dpp(v, std::integral_constant<int, 0x141>{});
+  if constexpr (G >= 16) v = v + dpp(v, std::integral_constant<int, 0x140>{});
+  if constexpr (G >= 32) v = v + __shfl_xor(v, 16);
+  if constexpr (G >= 64) v = v + __shfl_xor(v, 32);
+  return v;
+}
+// objective partials of the step lane: 0 volume, 1 target distance, 2 strain energy / 0 stress ratio, 1 deflection ratio, 2 bad pivot
+template <class LN>
+__device__ __forceinline__ double tb_group_sum_d(LN &ln, int which) {
+  return tb_group_reduce_sum<LN::G_>(which == 0 ? ln.p_vol : which == 1 ? ln.p_dt : ln.p_en);
+}
+template <class LN>
+__device__ __forceinline__ float tb_group_max_f(LN &ln, int which) {
+  return tb_group_reduce<LN::G_, true>(which == 0 ? ln.p_c1 : which == 1 ? ln.p_c2 : (float)ln.bad);
+}
+
+// EMIT workgroups: the word behind the progress word is set by a streaming wave that gave up waiting (tb_obs_timeout)
+template <class LN, class TD>
+__device__ __forceinline__ bool tb_obs_timed_out(LN &ln, const TD &T) {
+  if constexpr (LN::EMIT_) return *((const __attribute__((address_space(3))) int *)(ln.TB + T.o_flag) + 1) != 0;
+  return false;
+}
+
 #include "truss_body.h"
 
-// Progress word of an EMIT workgroup (LDS): the compute wave raises it, the streaming wave sleeps on it.
-// LDS operations of one wave execute in issue order, so the plain store of the word is ordered behind every
-// LDS store the compute wave issued before it, and the streaming wave's reads behind its read of the word;
-// the wavefront-scope fences only pin the compiler.
+// Progress word of an EMIT workgroup (LDS): the compute wave raises it, the streaming wave sleeps on it.  Everything the two waves
+// hand over lives in LDS, so the hand-off is a workgroup-scope release store / acquire load of an LDS word: on gfx950 (waves of a
+// workgroup share the CU, LDS operations of a wave retire in issue order) that is `s_waitcnt lgkmcnt(0); ds_write_b32` on one side
+// and `ds_read_b32; s_waitcnt lgkmcnt(0)` on the other.  The pointer MUST carry the LDS address space: through a generic
+// `volatile int *` (rounds 1-2) the compiler emitted flat_store / flat_load ... sc0 sc1 + s_waitcnt vmcnt(0), i.e. every publish and
+// every poll went through the vector-memory path and waited for ALL outstanding global stores of the wave.
+typedef __attribute__((address_space(3))) int tb_lds_word;
+__device__ __forceinline__ tb_lds_word *tb_flag_ptr(char *lds, int o_flag) { return (tb_lds_word *)(lds + o_flag); }
 __device__ __forceinline__ void tb_publish(char *lds, int o_flag, int k) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (threadIdx.x == 0) *(volatile int *)(lds + o_flag) = k;
+  if (threadIdx.x == 0) __hip_atomic_store(tb_flag_ptr(lds, o_flag), k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// false = gave up after ~7 s (the compute wave never got there: a fault is being reported elsewhere); the bound keeps
-// the grid draining in every case.  A compute wave publishes within tens of microseconds.
+// Bounded wait of the streaming wave for progress >= k.  false = gave up (the compute wave never got there -- it faulted or the
+// launch is being torn down); the caller then flags the env in status[] (TRUSS_STATUS_OBS_TIMEOUT) instead of streaming garbage.
+// The bound (~2^22 polls of >= 64 clocks: >= 0.1 s) keeps the grid draining in every case; a compute wave publishes within tens of
+// microseconds.  `tb_await_limit` is lowered by the emulator-side test of the timeout path only.
+#ifndef TB_AWAIT_SPINS
+#define TB_AWAIT_SPINS (1 << 22)
+#endif
 __device__ __forceinline__ bool tb_await(char *lds, int o_flag, int k) {
-  for (int spin = 0; spin < (1 << 26); ++spin) {
-    const int v = *(volatile int *)(lds + o_flag);
-    if (__builtin_amdgcn_readfirstlane(v) >= k) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      return true;
-    }
-    __builtin_amdgcn_s_sleep(4);
+  for (int spin = 0; spin < TB_AWAIT_SPINS; ++spin) {
+    const int v = __hip_atomic_load(tb_flag_ptr(lds, o_flag), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_readfirstlane(v) >= k) return true;
+    __builtin_amdgcn_s_sleep(1);
   }
   return false;
+}
+
+// the streaming wave gave up (tb_await): leave the timeout word for the compute wave's status store and raise the bit directly too
+template <class LN>
+__device__ __forceinline__ void tb_obs_timeout(LN &ln, char *lds, int o_flag, int32_t *status) {
+  if ((threadIdx.x & 63) == 0) *(tb_flag_ptr(lds, o_flag) + 1) = 1;
+  if (ln.g == 0 && ln.active && status) atomicOr(&status[ln.env], TRUSS_STATUS_OBS_TIMEOUT);
 }
 
 template <int G, int WL, int RPL, int EPL, bool EMIT>
@@ -161,7 +212,10 @@ __global__ __launch_bounds__(EMIT ? 128 : 64) void truss_step_kernel(const TopoD
   constexpr bool EMIT_ = EMIT;
   if constexpr (EMIT) {
     // two wavefronts: 0 computes the step, 1 streams the observation tensors (truss_body.h, "WHO streams")
-    if (threadIdx.x == 0) *(volatile int *)(smem + T.o_flag) = 0;
+    if (threadIdx.x == 0) {
+      *tb_flag_ptr(smem, T.o_flag) = 0;
+      *(tb_flag_ptr(smem, T.o_flag) + 1) = 0;   // timeout word
+    }
     __syncthreads();   // the only workgroup barrier of the kernel: the progress word starts at 0
     if (threadIdx.x >= 64) {
 #define SPH(call) \
@@ -174,24 +228,34 @@ __global__ __launch_bounds__(EMIT ? 128 : 64) void truss_step_kernel(const TopoD
   do {                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     if (threadIdx.x == 64 && blockIdx.x == gridDim.x / 2) g_truss_stamps[i] = clock64();              \
+    if (threadIdx.x == 64 && ((i) == 20 || (i) == 26) && blockIdx.x < 4096)                           \
+      g_truss_span[blockIdx.x][(i) == 20 ? 4 : 5] = wall_clock64();                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   } while (0)
 #else
 #define SST(i)
 #endif
       ln.emit_tables_load(T);   // ahead of every store of this wave in the vmcnt order
-      if (!tb_await(smem, T.o_flag, 1)) return;
-      SST(20);
-      TRUSS_STREAM_SEG1(SPH, T, A)
-      SST(21);
-      if (!tb_await(smem, T.o_flag, 2)) return;
-      SST(22);
-      TRUSS_STREAM_SEG2(SPH, T, A)
-      SST(23);
-      if (!tb_await(smem, T.o_flag, 3)) return;
-      SST(24);
-      TRUSS_STREAM_SEG3(SPH, T, A)
-      SST(25);
+      bool ok = tb_await(smem, T.o_flag, 1);
+      if (ok) {
+        SST(20);
+        TRUSS_STREAM_SEG1(SPH, T, A)
+        SST(21);
+        ok = tb_await(smem, T.o_flag, 2);
+      }
+      if (ok) {
+        SST(22);
+        TRUSS_STREAM_SEG2(SPH, T, A)
+        SST(23);
+        ok = tb_await(smem, T.o_flag, 3);
+      }
+      if (ok) {
+        SST(24);
+        TRUSS_STREAM_SEG3(SPH, T, A)
+        SST(25);
+      } else {
+        tb_obs_timeout(ln, smem, T.o_flag, A.status);   // one exit for the three waits
+      }
 #ifdef TRUSS_STAMPS
       __builtin_amdgcn_s_waitcnt(0);   // all stores of this wave retired (vmcnt(0))
       SST(26);
@@ -216,7 +280,11 @@ __global__ __launch_bounds__(EMIT ? 128 : 64) void truss_step_kernel(const TopoD
   TB_WAVE_SYNC()
 #define PH_NS(call) ln.call
 #define BAR() TB_WAVE_SYNC()
+#ifdef TRUSS_FAULT_DROP_PUBLISH3   // fault-injection build (make faultinj; tests only): progress 3 is never announced
+#define EMIT_POINT(k) do { if ((k) != 3) tb_publish(smem, T.o_flag, k); } while (0)
+#else
 #define EMIT_POINT(k) tb_publish(smem, T.o_flag, k)
+#endif
   TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
 #undef PH
 #undef PH_NS
@@ -543,7 +611,7 @@ static int tb_launch_step(const truss_topo *t, const StepArgsDev &A, bool emit, 
 
 #ifdef TRUSS_STAMPS
 extern "C" int truss_debug_span(unsigned long long *out, int nblocks) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_truss_span), (size_t)nblocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_truss_span), (size_t)nblocks * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 extern "C" int truss_debug_stamps32(unsigned long long *out32) {
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_truss_stamps), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;

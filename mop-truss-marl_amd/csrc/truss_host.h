@@ -175,7 +175,7 @@ static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res
     }
     return true;
   };
-  if (!place({{&D.b_erec, 8 * (E + 1)}, {&D.b_const, 3}}, early)) return false;   // written with the member results
+  if (!place({{&D.b_tc, 2 * (E + 1)}, {&D.b_erec, 4 * E}, {&D.b_erec2, 2 * E}, {&D.b_const, 3}}, early)) return false;   // written with / right behind the member results
   for (const TbFrag &f : early) late.push_back(f);                                   // what the element records left over
   if (!place({{&D.b_nna, 4 * N}, {&D.b_nnb, 4 * N}, {&D.b_nraw, 4 * N}, {&D.b_nn8, N}}, late)) return false;
   if (D.env_stride / 4 > 65535 || E + 1 > 65535) return false;
@@ -202,8 +202,8 @@ static bool tb_build_emit(truss_topo *t, const int32_t *conn, const uint8_t *res
     for (int c = 0; c < 12; ++c) tnxn.push_back((uint16_t)src[c]);
   }
   for (int e = 0; e < E; ++e) {
-    const int er = D.b_erec + 8 * e;   // sec, area, length, tension, compression, violated, (A_n_ts, A_n_cs)
-    const int own[7] = {er + 0, er + 1, er + 2, er + 3, er + 4, fQ0 + e, er + 5};
+    const int er = D.b_erec + 4 * e, er2 = D.b_erec2 + 2 * e;   // (sec, area, length, tension), (compression, violated)
+    const int own[7] = {er + 0, er + 1, er + 2, er + 3, er2 + 0, fQ0 + e, er2 + 1};
     for (int c = 0; c < 7; ++c) tnxe.push_back((uint16_t)own[c]);
     for (int q = 0; q < 2; ++q) {
       const int n = conn[2 * e + q];
@@ -610,7 +610,14 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
       uint8_t fl = nflags[nd >> 1];
       zcode[(size_t)tm * zlen + pz] = (uint8_t)((nd & 1) | ((fl & TF_LOAD_BRIDGE) ? 2 : 0) | ((fl & TF_LOAD_ROOF) ? 4 : 0));
     }
-  size_t o_ad = tb_push(blob, adj8), o_do = tb_push(blob, diagoff), o_zc = tb_push(blob, zcode);
+  // slots of every element's four end displacements in the solution vector (restrained -> the zero slot)
+  std::vector<int16_t> exs(4 * (size_t)E);
+  for (int e = 0; e < E; ++e)
+    for (int q = 0; q < 4; ++q) {
+      const int dp = dofpos[2 * conn[2 * e + (q >> 1)] + (q & 1)];
+      exs[4 * (size_t)e + q] = (int16_t)(dp < 0 ? zslot : dp);
+    }
+  size_t o_ad = tb_push(blob, adj8), o_do = tb_push(blob, diagoff), o_zc = tb_push(blob, zcode), o_exs = tb_push(blob, exs);
   blob.resize((blob.size() + 15) & ~size_t(15));
   TopoDev &D = t->dev;
   D.N = N;
@@ -640,6 +647,7 @@ extern "C" int truss_topo_create(truss_topo_t **out, int32_t N, int32_t E, const
   D.f_adj8 = (int32_t)o_ad;
   D.f_diagoff = (int32_t)o_do;
   D.f_zcode = (int32_t)o_zc;
+  D.f_exs = (int32_t)o_exs;
   D.nteams = nteams;
   D.KA = KA;
   D.mid = mid;
@@ -783,6 +791,7 @@ static int tb_make_step_args(const truss_topo_t *t, const truss_step_args_t *a, 
   if (!a->x || !a->y_in || !a->sec_in || !a->target || !a->env_params || !a->y_out || !a->disp || !a->q0 || !a->sr ||
       !a->comp || !a->point)
     return tb_fail(TRUSS_EINVAL, "a required device pointer is NULL");
+  if (((size_t)a->point & 15) != 0 || ((size_t)a->obj & 7) != 0) return tb_fail(TRUSS_EINVAL, "point must be 16-byte aligned, obj 8-byte aligned");
   if (decode && (!a->a_geo || !a->a_topo)) return tb_fail(TRUSS_EINVAL, "actions are NULL");
   if (decode && !t->dev.has_pairs) return tb_fail(TRUSS_EINVAL, "action decode needs a vertical-pair table");
   if ((a->max_up_in == nullptr) != (a->max_down_in == nullptr)) return tb_fail(TRUSS_EINVAL, "max_up_in/max_down_in must come together");

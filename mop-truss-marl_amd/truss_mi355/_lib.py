@@ -18,6 +18,8 @@ TRUSS_ABI_VERSION = 3
 F_NO_DECODE = 0x1
 F_CLAMP_INPLACE = 0x2
 F_EMIT_OBS = 0x4
+STATUS_NOT_SPD = 1        # status[] bits (include/truss_mi355.h)
+STATUS_OBS_TIMEOUT = 2
 NPARAM = 8
 P_YMAX, P_DMIN, P_MAXDEF, P_LOADX, P_LOADY, P_INTOBJ1, P_INTOBJ2, P_ISROOF = range(8)
 

@@ -258,6 +258,20 @@ class BatchedTruss:
                           out.get("x_n"), out.get("A_s"), out.get("A_n_ts"), out.get("A_n_cs"), out.get("nN_x_n"), out.get("nN_x_e"))
         return out
 
+    def check(self):
+        """Synchronising health check of the last native call (status[B], include/truss_mi355.h): raises TrussError when an env's
+        stiffness matrix was not positive definite (bit 0: the reference would raise LinAlgError, FEM_2Dtruss.py:337) or when the
+        fused observation writer gave up waiting for a step's results (bit 1: the observation tensors of that call are incomplete).
+        Long-running loops call it at episode boundaries; a step itself never synchronises."""
+        st = self.status
+        bad = int((st & _lib.STATUS_NOT_SPD).ne(0).sum().item())
+        late = int((st & _lib.STATUS_OBS_TIMEOUT).ne(0).sum().item())
+        if late:
+            raise _lib.TrussError(f"{late} env(s): the observation stream of the fused step timed out (TRUSS_STATUS_OBS_TIMEOUT); "
+                                  "the observation tensors of the last step are incomplete")
+        if bad:
+            raise _lib.TrussError(f"{bad} env(s): non-positive pivot (K not SPD)")
+
     def results(self):
         """Host copies (numpy) of the last step's outputs."""
         g = lambda t: t.detach().cpu().numpy()

@@ -18,6 +18,7 @@ struct float4 {
 #define TRUSS_HD inline
 #define TRUSS_UNROLL
 #define TB_STREAM_STORE(p, v) (*(p) = (v))
+#define TB_OBS_STORE(p, v) (*(p) = (v))
 static inline void tb_lds_add(double *p, double v) { *p += v; }
 static inline double tb_rcp(double d) { return 1.0 / d; }
 // The emulator's lanes know their wave (cross-lane stand-ins below); the product's lane struct does not.
@@ -45,6 +46,32 @@ static inline float tb_group_max(LN &ln, int c) {
   for (int j = 0; j < LN::G_; ++j) v = fmaxf(v, emu_peers(ln)[ln.lane - ln.g + j].pmx[c]);
   return v;
 }
+
+// objective partials folded over the lanes of an env (HIP: DPP butterfly; the float64 sums of float32 terms are exact)
+template <class LN>
+static inline double tb_group_sum_d(LN &ln, int which) {
+  double v = 0.0;
+  for (int j = 0; j < LN::G_; ++j) {
+    const LN &p = emu_peers(ln)[ln.lane - ln.g + j];
+    v += which == 0 ? p.p_vol : which == 1 ? p.p_dt : p.p_en;
+  }
+  return v;
+}
+template <class LN>
+static inline float tb_group_max_f(LN &ln, int which) {
+  float v = 0.0f;
+  for (int j = 0; j < LN::G_; ++j) {
+    const LN &p = emu_peers(ln)[ln.lane - ln.g + j];
+    v = fmaxf(v, which == 0 ? p.p_c1 : which == 1 ? p.p_c2 : (float)p.bad);
+  }
+  return v;
+}
+
+// TRUSS_EMU_FORCE_OBS_TIMEOUT=1 (tests of the status plumbing): segments 2 and 3 of the observation stream behave as if the
+// streaming wave had given up waiting -- nothing is written, status gets TRUSS_STATUS_OBS_TIMEOUT
+static int g_emu_force_obs_timeout = 0;
+template <class LN, class TD>
+static inline bool tb_obs_timed_out(LN &, const TD &) { return LN::EMIT_ && g_emu_force_obs_timeout != 0; }
 
 #include "../../mop-truss-marl_amd/csrc/truss_body.h"
 
@@ -83,7 +110,8 @@ static void emu_run(const truss_topo *t, const StepArgsDev &A) {
 #define PH_NS(call) \
   for (auto &ln : lanes) ln.call
 #define BAR() (void)0
-#define EMIT_POINT(k) TRUSS_STREAM_SEG##k(PH, T, A)   /* HIP: the streaming wave's work; here: in place */
+#define EMIT_POINT(k) if (!(g_emu_force_obs_timeout && (k) >= 2)) { TRUSS_STREAM_SEG##k(PH, T, A) }   /* HIP: the streaming wave's work; here: in place */
+    g_emu_force_obs_timeout = getenv("TRUSS_EMU_FORCE_OBS_TIMEOUT") && atoi(getenv("TRUSS_EMU_FORCE_OBS_TIMEOUT"));
     TRUSS_STEP_SCHEDULE(PH, PH_NS, BAR, T, A)
 #undef PH
 #undef PH_NS

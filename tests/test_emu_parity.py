@@ -55,6 +55,38 @@ def test_fused_observation_random_emulated(lib):
     pc.run_obs_random(lib, 5, 0, 3, seed=25, fused=True, expect_one_launch=False)    # 10 / 21: N % 4 != 0 -> two launches
 
 
+def test_observation_timeout_status_plumbing_emulated(lib, monkeypatch):
+    """TRUSS_STATUS_OBS_TIMEOUT end to end on the host side: when the observation stream of the fused step gives up (forced in
+    the emulator; the GPU test test_observation_timeout_is_reported runs the real bounded wait on a fault-injection build) the
+    step's own results are complete, status carries bit 1 for every env, the late tensors are untouched and check() raises."""
+    topo = synthetic.bench_topology(16, 4)
+    B = 6
+    batch = synthetic.random_batch(topo, B, 5)
+    ag, at = synthetic.random_actions(1, B, topo.N, 6)
+    e_ok, e_to = pc.make_env(lib, topo, batch), pc.make_env(lib, topo, batch)
+    for e in (e_ok, e_to):
+        e.analyze(set_normalisers=True)
+    g0, t0 = torch.tensor(ag[0]), torch.tensor(at[0])
+    e_ok.step(g0.clone(), t0.clone(), obs=True)
+    e_ok.check()
+    monkeypatch.setenv("TRUSS_EMU_FORCE_OBS_TIMEOUT", "1")
+    got = {k: torch.full_like(v, float("nan")) for k, v in e_to.obs_buffers().items()}
+    e_to.step(g0.clone(), t0.clone(), obs=got)
+    monkeypatch.delenv("TRUSS_EMU_FORCE_OBS_TIMEOUT")
+    st = e_to.status.numpy()
+    assert np.all(st & tm._lib.STATUS_OBS_TIMEOUT) and not np.any(st & tm._lib.STATUS_NOT_SPD)
+    for k in ("y", "sec", "point", "q0", "sr", "disp"):
+        assert np.array_equal(e_to.results()[k], e_ok.results()[k]), k
+    assert torch.equal(got["A_s"], e_ok.obs_buffers()["A_s"])                       # segment 1 ran
+    for k in ("A_n_ts", "A_n_cs", "x_n", "nN_x_n", "nN_x_e"):
+        assert torch.isnan(got[k]).all(), k                                          # segments 2 and 3 did not
+    with pytest.raises(tm.TrussError, match="timed out"):
+        e_to.check()
+    e_to.step(g0.clone(), t0.clone(), obs=got)                                       # the next call is clean again
+    e_to.check()
+    assert not any(torch.isnan(v).any() for v in got.values())
+
+
 def test_fused_observation_any_element_count_emulated(lib):
     """element counts of every residue mod 4: nN_x_e rows (21 E floats per env) are 16-, 8- or 4-byte aligned per env"""
     for k in range(4):

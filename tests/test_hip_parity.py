@@ -103,6 +103,44 @@ def test_fused_observation_full_size(lib):
         np.testing.assert_allclose(got2[k].cpu().numpy(), ref2[k].cpu().numpy(), rtol=4e-7, atol=1e-7, err_msg=k)
 
 
+def test_observation_timeout_is_reported(lib):
+    """The bounded wait of the streaming wavefront, for real: a fault-injection build of the same kernel (`make all` builds
+    libtruss_mi355_faultinj.so: the compute wave never announces progress 3, the wait is 20 000 polls) must drain, write the
+    step's own results, leave the tensors of the missing segment untouched and raise TRUSS_STATUS_OBS_TIMEOUT for every env --
+    through the streaming wave's own atomic OR (the compute wave has stored status before the wait ends)."""
+    import os
+    path = os.path.join(os.path.dirname(tm._lib.DEFAULT_LIB), "libtruss_mi355_faultinj.so")
+    assert os.path.exists(path), "make -C mop-truss-marl_amd/csrc all"
+    flib = tm.load(path)
+    assert flib.backend == "hip"
+    topo = synthetic.bench_topology(16, 4)
+    B = 258                                            # ragged last workgroup
+    batch = synthetic.random_batch(topo, B, 5)
+    ag, at = synthetic.random_actions(1, B, topo.N, 6)
+    e_ok, e_to = pc.make_env(lib, topo, batch), pc.make_env(flib, topo, batch)
+    assert e_to.fused_obs
+    for e in (e_ok, e_to):
+        e.analyze(set_normalisers=True)
+    g0, t0 = torch.tensor(ag[0], device=e_ok.device), torch.tensor(at[0], device=e_ok.device)
+    ref = e_ok.step(g0.clone(), t0.clone(), obs=True)
+    e_ok.check()
+    got = {k: torch.full_like(v, float("nan")) for k, v in e_to.obs_buffers().items()}
+    e_to.step(g0.clone(), t0.clone(), obs=got)
+    torch.cuda.synchronize()
+    st = e_to.status.cpu().numpy()
+    assert np.all(st & tm._lib.STATUS_OBS_TIMEOUT), st
+    assert not np.any(st & tm._lib.STATUS_NOT_SPD)
+    r_ok, r_to = e_ok.results(), e_to.results()
+    for k in ("y", "sec", "point", "q0", "sr", "disp", "comp"):
+        assert np.array_equal(r_to[k], r_ok[k]), k
+    for k in ("A_s", "A_n_ts", "A_n_cs"):                                            # segments 1 and 2 ran
+        assert torch.equal(got[k], ref[k]), k
+    for k in ("x_n", "nN_x_n", "nN_x_e"):                                            # segment 3 gave up
+        assert torch.isnan(got[k]).all(), k
+    with pytest.raises(tm.TrussError, match="timed out"):
+        e_to.check()
+
+
 def test_fused_observation_soak(lib):
     """60 chained state-emitting steps at 4096 envs on two copies of the same batch: every step's observation tensors and results are
     bitwise equal between the copies (the two-wavefront launch -- compute wave + streaming wave over LDS progress words -- is

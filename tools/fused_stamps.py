@@ -25,7 +25,12 @@ env.set_design(batch["y"], batch["sec"])
 env.analyze(set_normalisers=True)
 ag, at = synthetic.random_actions(2, B, topo.N, 2)
 G, T = torch.tensor(ag[0], device=env.device), torch.tensor(at[0], device=env.device)
-ob = env.obs_buffers()
+full = env.obs_buffers()
+SUB = {"all": full, "none": None, "rows_only": {k: full[k] for k in ("x_n", "nN_x_n", "nN_x_e")},
+       "matrices_only": {k: full[k] for k in ("A_s", "A_n_ts", "A_n_cs")}, "A_s_only": {"A_s": full["A_s"]},
+       "no_A_s": {k: v for k, v in full.items() if k != "A_s"}}
+which = sys.argv[3] if len(sys.argv) > 3 else "all"
+ob = SUB[which]
 for _ in range(20):
     env.step(G, T, obs=ob)
 torch.cuda.synchronize()
@@ -48,6 +53,20 @@ e0.record()
 for _ in range(100):
     env.step(G, T, obs=ob)
 e1.record(); torch.cuda.synchronize()
-print(f"fused={env.fused_obs} B={B}; stamped launch {e0.elapsed_time(e1) * 10:.2f} us; cycles since the compute wave's start (mid-grid workgroup)")
+print(f"subset={which} fused={env.fused_obs} B={B}; stamped launch {e0.elapsed_time(e1) * 10:.2f} us; cycles since the compute wave's start (mid-grid workgroup)")
 for (i, n), c in sorted(zip(EVENTS, acc), key=lambda t: t[1]):
     print(f"   {c:9.0f}  {n}")
+
+# spread of the workgroups over the launch (wall clock, 100 MHz): first start -> last end of either wave
+nb = B * topo.solver_info(lib)["lanes_per_env"] // 64
+env.step(G, T, obs=ob); torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (6 * nb))()
+lib.dll.truss_debug_span.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.dll.truss_debug_span(buf, nb) == 0
+a = np.array(list(buf), dtype=np.float64).reshape(nb, 6)
+t0 = a[:, 1].min()
+cs, ce, se = (a[:, 1] - t0) * 10, (a[:, 3] - t0) * 10, (a[:, 5] - t0) * 10
+print(f"workgroups {nb}: compute-wave start  median {np.median(cs):.0f} ns, 90% {np.percentile(cs, 90):.0f}, max {cs.max():.0f}")
+print(f"   compute-wave end    median {np.median(ce):.0f} ns, max {ce.max():.0f};   duration median {np.median(ce - cs):.0f} ns")
+if ob is not None:
+    print(f"   streaming-wave end  median {np.median(se):.0f} ns, max {se.max():.0f}")

@@ -33,10 +33,10 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); env.rollout(G, T, 200); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 200
-    buf = (ctypes.c_ulonglong * (4 * nb))()
+    buf = (ctypes.c_ulonglong * (6 * nb))()
     lib.dll.truss_debug_span.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert lib.dll.truss_debug_span(buf, nb) == 0
-    a = np.array(list(buf), dtype=np.float64).reshape(nb, 4)
+    a = np.array(list(buf), dtype=np.float64).reshape(nb, 6)
     cyc = a[:, 2] - a[:, 0]
     wall = (a[:, 3] - a[:, 1]) * 10.0   # ns (100 MHz)
     span_ns = (a[:, 3].max() - a[:, 1].min()) * 10.0
