@@ -8,10 +8,16 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   shards with no data-path collective.
 
 A "step" is ONE pass of the hot path over the whole resident batch: one `_game_modify`-equivalent per env
-(action decode -> design update -> FP64 assembly + solve -> member stresses -> point), i.e. one launch of
-truss_step_kernel over the rank's envs.  Workload = BASELINE.json's metric config: synthetic random-geometry
-trusses, 32 nodes / 80 elements / 60 DOF, FEM-only (no agent).  Inputs (design state, per-env constants, a pool
-of pre-drawn actions) are resident in HBM before the timed region starts.
+(action decode -> design update -> FP64 assembly + solve -> member stresses -> point).  Workload = BASELINE.json's
+metric config: synthetic random-geometry trusses, 32 nodes / 80 elements / 60 DOF, FEM-only (no agent).  Inputs
+(design state, per-env constants, a pool of pre-drawn actions) are resident in HBM before the timed region starts.
+
+`value` is the path an AGENT CAN DRIVE: one launch of truss_step_kernel per step (`truss_step`; the K launches of a
+timed block are issued back to back by the C entry `truss_rollout` in its one-launch-per-step mode, exactly what a
+replayed hipGraph of K `truss_step` calls does) -- the reference never chains steps with actions known up front
+(master_DDPG_truss2D_MO.py:249-260).  The persistent K-steps-in-one-launch kernel (`truss_rollout_kernel`) is reported
+next to it as `persistent_rollout`, the state-emitting step (`TRUSS_F_EMIT_OBS`, what configs[2]-[4] execute) as
+`state_emitting_step`, and a time-boxed `configs` object carries BASELINE configs[2]-[4] (bench_configs.py).
 
   --scaling weak    (default) 4096 envs PER GPU ("at 4096 envs" is the kernel's design point: one wave per SIMD)
   --scaling strong  --global-envs (default 4096; BASELINE configs[3] is 8192) split contiguously over the ranks
@@ -113,7 +119,20 @@ def cpu_baseline():
             "sample": f"{n_steps} steps x {shard * cores} envs (32 nodes / 80 elements, same generator) on {cores} processes x 1 thread, "
                       f"numpy oracle; wall time of the pool incl. its slowest worker",
             "single_env_ms_per_step": t1 / n1 * 1e3, "cpu_model": model, "host_cores_visible": avail,
-            "reference_note": "the reference's own _game_modify: BASELINE.md (this container, 1 core)"}
+            "reference_note": reference_note()}
+
+
+def reference_note():
+    """The reference's own CPU path, timed in the build container by tools/time_reference.py (it does not travel to the GPU box)."""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r3", "reference_cpu.json")))
+        c = r["cases"]["large_bridge"]
+        return {"source": "profiles/r3/reference_cpu.json (tools/time_reference.py, build container, 1 core, median of 5 x 100 calls)",
+                "cpu_model": r["cpu_model"], "truss": f"{c['nodes']} nodes / {c['elements']} elements (the reference's own large truss)",
+                "_game_modify_ms": c["_game_modify"]["ms_per_call_median"], "gen_all_ms": c["gen_all"]["ms_per_call_median"],
+                "env_steps_per_s_per_core": c["_game_modify"]["calls_per_s_per_core"]}
+    except (OSError, KeyError, ValueError):
+        return "the reference's own _game_modify: BASELINE.md (build container, 1 core)"
 
 
 # ---- launching ---------------------------------------------------------------------------------------------
@@ -147,17 +166,56 @@ def measure(env, G, T, steps, warmup, dist, distributed):
 
 
 def committed_traffic(root, envs, N, E):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary, if it was taken on this kernel source."""
-    p = os.path.join(root, "profiles", "r2", "pmc_traffic.json")
+    """HBM bytes per launch / per step from the committed rocprofv3 PMC summary (profiles/r3/pmc_traffic.json), if it was taken on
+    this kernel source: {"step": .., "rollout": .., "fused": ..} or {}."""
+    p = os.path.join(root, "profiles", "r3", "pmc_traffic.json")
     try:
         rec = json.load(open(p))
         src = open(os.path.join(root, "mop-truss-marl_amd", "csrc", "truss_body.h"), "rb").read()
         if rec.get("envs") == envs and rec.get("nodes") == N and rec.get("elements") == E and \
                 rec.get("truss_body_sha16") == hashlib.sha256(src).hexdigest()[:16]:
-            return rec.get("step_kernel_bytes_per_launch")
+            return {"step": rec.get("step_kernel_bytes_per_launch"), "rollout": rec.get("rollout_kernel_bytes_per_step"),
+                    "fused": rec.get("fused_step_kernel_bytes_per_launch")}
     except (OSError, ValueError):
         pass
-    return None
+    return {}
+
+
+def run_configs(args, tm, lib, dev, dist, rank, world, budget_s):
+    """BASELINE configs[2]-[4] (bench_configs.py), time-boxed: an entry that would start after the budget is spent is recorded as
+    skipped; an entry that raises is recorded with its error -- the headline line is printed in every case.  The single-GPU
+    entries run when there is one rank; large_bridge runs on the ranks present (its env batch shards, the MADDPG gradients are
+    all-reduced over RCCL)."""
+    import bench_configs as BC
+    out, t0 = {}, time.perf_counter()
+
+    def entry(name, fn, collective=False):
+        left = budget_s - (time.perf_counter() - t0)
+        go = left > 0
+        if collective and dist is not None:      # all ranks take the same decision
+            import torch
+            f = torch.tensor([1 if go else 0], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            go = bool(f.item())
+        if not go:
+            out[name] = {"skipped": f"time box of {budget_s:.0f} s spent"}
+            return
+        try:
+            r = fn()
+            out[name] = {k: v for k, v in r.items() if k not in ("profile_s", "config")}
+            out[name]["workload"] = r.get("config")
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    if world == 1:
+        entry("marl_small_roof_4096", lambda: BC.marl_small_roof(4096, 4, True, dev=dev))
+        entry("marl_small_roof_4096_no_training", lambda: BC.marl_small_roof(4096, 4, False, dev=dev))
+        entry("mixed_pool_step", lambda: BC.mixed_pool_step(lib, dev))
+        entry("mixed_pool_marl_no_training", lambda: BC.mixed_marl(train=False, dev=dev))
+        entry("mixed_pool_marl", lambda: BC.mixed_marl(train=True, dev=dev))
+    entry("large_bridge_8192", lambda: BC.large_bridge(8192, 3, True, dev=dev, dist=dist, rank=rank, world=world), collective=True)
+    out["seconds"] = time.perf_counter() - t0
+    return out
 
 
 def main():
@@ -169,6 +227,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--global-envs", type=int, default=4096, help="total envs, split over the ranks (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the time-boxed BASELINE configs[2]-[4] object")
+    ap.add_argument("--configs-budget", type=float, default=90.0, help="seconds the configs object may take")
     ap.add_argument("--extras", action="store_true", help="also time the E=76 / small / large topologies (bench_extras.py)")
     ap.add_argument("--lib", default=None, help="diagnostic: another HIP build of the same ABI (default: the product library)")
     args = ap.parse_args()
@@ -222,16 +282,20 @@ def main():
         global_envs = args.global_envs
         B = shard_of(global_envs)
     env, G, T, _ = distributed.make_rank_env(topo, B, rank, device=dev, lib=lib, seed=1234, n_action_sets=N_ACTION_SETS)
+    # headline: ONE LAUNCH PER STEP (the path an agent can drive); every rank, barrier + max over ranks
+    os.environ["TRUSS_ROLLOUT_LAUNCHES"] = "1"
     elapsed, el_min, el_max, dev_ms = measure(env, G, T, args.steps, args.warmup, dist, distributed)
+    del os.environ["TRUSS_ROLLOUT_LAUNCHES"]
     st = int(env.status.sum().item())
-    one_launch = bool(env.persistent_rollout)            # the K chained steps of a block ran as ONE persistent launch
-    per_step_launches = None
-    if one_launch and on_gpu and rank == 0 and world == 1:
-        os.environ["TRUSS_ROLLOUT_LAUNCHES"] = "1"        # the same K steps as K launches (what round 1 measured)
-        w, wmin, wmax, d_ms = measure(env, G, T, args.steps, 0, dist, distributed)
-        del os.environ["TRUSS_ROLLOUT_LAUNCHES"]
-        per_step_launches = {"env_steps_per_s": global_envs * args.steps / w, "ms_per_step": w / args.steps * 1e3,
-                             "kernel_us": d_ms * 1e3 / args.steps, "kernel": "truss_step_kernel, one launch per step"}
+    # the same K chained steps as ONE persistent launch (actions known up front: a bench / population-optimiser path)
+    persistent = None
+    if bool(env.persistent_rollout):
+        w, wmin, wmax, d_ms = measure(env, G, T, args.steps, args.warmup, dist, distributed)
+        persistent = {"env_steps_per_s": global_envs * args.steps / w, "ms_per_step": w / args.steps * 1e3,
+                      "ms_per_step_min": wmin / args.steps * 1e3, "ms_per_step_max": wmax / args.steps * 1e3,
+                      "kernel_us": (d_ms * 1e3 / args.steps) if d_ms is not None else None, "steps_per_launch": args.steps,
+                      "kernel": "truss_rollout_kernel: the K chained steps of a block as ONE launch (actions known up front; "
+                                "no caller in the agent loop)"}
 
     strong = None
     if world > 1 and args.scaling == "weak":
@@ -271,6 +335,10 @@ def main():
                  "frac_of_hbm_peak_B_obs": B * b_ref / (so_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                  "frac_of_hbm_peak_bytes_moved": B * b_wr / (so_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
+    configs = None
+    if on_gpu and not args.no_configs:
+        configs = run_configs(args, tm, lib, dev, dist, rank, world, args.configs_budget)
+
     extras = {}
     if args.extras and rank == 0 and on_gpu:
         import bench_extras
@@ -281,6 +349,19 @@ def main():
         kern_s = (dev_ms * 1e-3 if dev_ms is not None else elapsed) / args.steps
         achieved = per_step_bytes / kern_s / 1e9
         info = topo.solver_info(lib)
+        traffic = committed_traffic(ROOT, B, topo.N, topo.E)
+        if persistent is not None and persistent["kernel_us"]:
+            ks = persistent["kernel_us"] * 1e-6
+            persistent["roofline"] = {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # bytes the kernel really moves per step (PMC; it keeps the design state in LDS and never re-reads it, so this
+                # is LESS than the algorithmic B_core) -- null without a committed profile of this kernel source
+                "traffic": traffic.get("rollout"),
+                "achieved_counter_bytes": (traffic["rollout"] / ks / 1e9) if traffic.get("rollout") else None,
+                "frac_counter_bytes": (traffic["rollout"] / ks / 1e9 / HBM_PEAK_GBS) if traffic.get("rollout") else None,
+                "achieved_B_core": per_step_bytes / ks / 1e9, "frac_B_core": per_step_bytes / ks / 1e9 / HBM_PEAK_GBS}
+        if state is not None:
+            state["traffic"] = traffic.get("fused")
         out = {
             "metric": "env steps/sec (batched FEM solves) at 4096 envs",
             "value": global_envs * args.steps / elapsed,
@@ -300,6 +381,7 @@ def main():
             "config": {
                 "workload": "synthetic random-geometry 2-row trusses, 32 nodes / 80 elements / 60 DOF, "
                             "FEM-only env.step (action decode + FP64 assembly/solve + stresses + point), no agent",
+                "path": "step: one launch of truss_step_kernel per env step (truss_step), K launches per timed block",
                 "envs_per_gpu": B, "global_envs": global_envs, "nodes": topo.N, "elements": topo.E,
                 "ndof": int(env.ndof), "half_bandwidth": info["half_bandwidth"],
                 "lanes_per_env": info["lanes_per_env"], "rows_per_lane": info["rows_per_lane"],
@@ -309,21 +391,19 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 # HBM bytes per launch: rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes) of
-                # THIS kernel source, from profiles/r2/pmc_traffic.json; null when the committed profile is of another build
-                "traffic": committed_traffic(ROOT, B, topo.N, topo.E),
-                # `kernel_us` / `bytes_per_launch` are PER STEP.  With the persistent rollout one launch of truss_rollout_kernel
-                # plays `steps_per_launch` chained steps (launch duration = steps_per_launch x kernel_us, algorithmic bytes =
-                # steps_per_launch x bytes_per_launch): the rocprofv3 average of that kernel divides the same way
-                "kernel": "truss_rollout_kernel" if one_launch else "truss_step_kernel", "kernel_us": kern_s * 1e6,
-                "steps_per_launch": args.steps if one_launch else 1, "launch_us": kern_s * 1e6 * (args.steps if one_launch else 1),
+                # THIS kernel source, from profiles/r3/pmc_traffic.json; null when the committed profile is of another build
+                "traffic": traffic.get("step"),
+                "kernel": "truss_step_kernel", "kernel_us": kern_s * 1e6, "steps_per_launch": 1, "launch_us": kern_s * 1e6,
                 "bytes_per_launch": per_step_bytes,
                 # the other two ceilings SURVEY §8d asks for (algorithmic banded flop count, 1e4 per env-step)
                 "fp64_gflops": 1.0e4 * B / kern_s / 1e9, "fp64_frac_of_78.6_TFLOPs": 1.0e4 * B / kern_s / 78.6e12,
             },
-            "one_launch_per_step": per_step_launches,
+            "persistent_rollout": persistent,
             "state_emitting_step": state,
             "nonpositive_pivots": st,
         }
+        if configs is not None:
+            out["configs"] = configs
         if strong:
             out["strong"] = strong
         if extras:

@@ -104,17 +104,5 @@ def run(tm, synthetic, lib, dev, topo, env, G, T, args, B):
         a1.record(); torch.cuda.synchronize()
         extras[tag]["us_per_pool_step_with_obs"] = a0.elapsed_time(a1) * 1e3 / 30
         del p
-    # BASELINE configs[2]: small_roof, 4096 envs, MADDPG GCN agents in the loop (tools/marl_bench.py)
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-    import marl_bench
-    for tag, train in (("marl_small_roof_4096", True), ("marl_small_roof_4096_no_training", False)):
-        r = marl_bench.run(4096, 4, train, 8)
-        extras[tag] = {k: r[k] for k in ("env_steps_per_s", "env_steps", "seconds", "mean_front", "game_steps")}
-    # BASELINE configs[4]: the mixed 32 / 64 / 128 / 256-node Pareto sweep with one set of agents (tools/marl_mixed_bench.py)
-    import marl_mixed_bench
-    for tag, train in (("marl_mixed_sweep", True), ("marl_mixed_sweep_no_training", False)):
-        r = marl_mixed_bench.run(train=train)
-        extras[tag] = {k: r[k] for k in ("env_steps_per_s", "env_steps", "seconds", "envs_per_class", "game_steps")}
+    # (BASELINE configs[2]-[4] -- the batched MADDPG rollout, the mixed sweep, large_bridge -- are in bench.py's default `configs` object)
     return extras

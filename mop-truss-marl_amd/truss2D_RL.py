@@ -221,19 +221,21 @@ def _fresh_adam_step(params, lr, eps):
         torch._foreach_add_(ps, upd, alpha=-lr)
 
 
-def _allreduce_grads(params, dist):
-    """One fused all-reduce of the flat gradient buffer (mean over ranks)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def _allreduce_grads(param_lists, dist):
+    """ONE all-reduce (mean over ranks) of the flat gradient buffer of every network in `param_lists` (a list of parameter
+    lists).  The buffer is built and scattered back by multi-tensor launches; inside a hipGraph capture the collective is
+    captured with the update (RCCL kernels on the capture stream)."""
+    if dist is None or not dist.is_initialized():
         return
-    grads = [p.grad for p in params if p.grad is not None]
+    grads = [p.grad for ps in param_lists for p in ps if p.grad is not None]
+    if not grads:
+        return
+    world = dist.get_world_size()
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= dist.get_world_size()
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
-        off += n
+    if world > 1:
+        flat.mul_(1.0 / world)
+    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
 
 class multimodals_OneAgent:
@@ -391,6 +393,9 @@ class MADDPG:
                 q = ag.target_critic_model(NSc + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1], na[o[2]][0], na[o[2]][1]])
                 for f in range(3):
                     q_next[f][i] = q[f * nb:(f + 1) * nb]
+        # The three critic updates depend on nothing another network's update changes (replayed actions, target networks): they
+        # come first -- exactly the reference's results, since critic i is not touched between its own step and agent i's actor
+        # update (:603-629) -- and, data-parallel, their gradients travel as ONE flat buffer (one RCCL all-reduce for the three).
         for i, ag in enumerate(self.agents):
             o = orders[i]
             # TD target; `done` never fires in the reference (it compares an action array with `is 1`)
@@ -398,12 +403,16 @@ class MADDPG:
             ag.critic_opt.zero_grad(set_to_none=True)
             loss = torch.mean((ag.critic_model(S + flat(o)) - y) ** 2)
             loss.backward()
-            cp = list(ag.critic_model.parameters())
-            _allreduce_grads(cp, self.dist)
+            ag.c_loss.append(loss.detach())          # stays on the device: no synchronisation inside the update
+        cps = [list(ag.critic_model.parameters()) for ag in self.agents]
+        _allreduce_grads(cps, self.dist)
+        for ag, cp in zip(self.agents, cps):
             _clip_each(cp)
             ag.critic_opt.step()
-            ag.c_loss.append(loss.detach())          # stays on the device: no synchronisation inside the update
-            # actor: maximise the own critic with all three actors re-evaluated (:617-629)
+        # The actor updates stay one after the other: agent i's loss re-evaluates ALL three actors (:617-629), i.e. it sees the
+        # weights agents < i have just stepped to -- one collective per actor.
+        for i, ag in enumerate(self.agents):
+            o = orders[i]
             preds = [a2.actor_model(self._actor_in(S)) for a2 in self.agents]
             q = ag.critic_model(S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
                                      preds[o[2]][1]])
@@ -414,7 +423,7 @@ class MADDPG:
             grads = torch.autograd.grad(actor_loss, ap, allow_unused=True)
             for p, g in zip(ap, grads):
                 p.grad = g
-            _allreduce_grads(ap, self.dist)
+            _allreduce_grads([ap], self.dist)
             _clip_each(ap)
             _fresh_adam_step(ap, ag.lr * 0.1, 1e-7)                                      # a fresh optimiser every call (:629)
 
@@ -422,7 +431,7 @@ class MADDPG:
         """Data-parallel start: every rank takes rank `src`'s actor / critic / target weights (one broadcast
         of a flat buffer per network).  Call once the lazy layers exist (after the first forward)."""
         d = self.dist
-        if d is None or not d.is_initialized() or d.get_world_size() == 1:
+        if d is None or not d.is_initialized():
             return
         for ag in self.agents:
             for net in (ag.actor_model, ag.target_actor_model, ag.critic_model, ag.target_critic_model):

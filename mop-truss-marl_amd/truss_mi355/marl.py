@@ -335,12 +335,11 @@ class BatchedMARL:
 
     # ---- the MADDPG update: eager, or (one GPU) replayed as a hipGraph ----
     def _train(self, S, NS, A, R):
-        """The update is thousands of small kernels at batch 32 -- launch-bound.  On a single GPU it is captured
-        once into a hipGraph (static input buffers, capturable Adam) and replayed; with a process group (the
-        gradient all-reduce is a collective) or on the CPU backend it runs eagerly."""
-        d = getattr(self.rl, "dist", None)
-        multi = d is not None and d.is_initialized() and d.get_world_size() > 1
-        if self.device.type != "cuda" or multi or not self.use_train_graph:
+        """The update is thousands of small kernels at batch 32 -- launch-bound.  On the GPU it is captured once into a hipGraph
+        (static input buffers, capturable Adam) and replayed -- data-parallel too: the gradient all-reduces (RCCL; one flat
+        buffer for the three critics, one per actor) are captured WITH the update, every rank replaying its own copy of the same
+        graph.  On the CPU backend (gloo tests) it runs eagerly."""
+        if self.device.type != "cuda" or not self.use_train_graph:
             return self.rl.train_on_batch(S, NS, A, R)
         flat_in = list(S) + [t for ns in NS for t in ns] + [t for a in A for t in a] + [R]
         if self._tg is None:
