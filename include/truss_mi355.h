@@ -279,6 +279,47 @@ int truss_gcn_aggregate_sparse(const float *adj, int64_t a_batch_stride, const i
                                const float *bias, float *out, int32_t n_batch, int32_t n_nodes, int32_t n_channels, int32_t act,
                                void *stream);
 
+/* ---- one whole GCN layer on the matrix cores -------------------------------------------------------------
+ * replaces: spektral GCNConv as the reference's actors / critics call it (truss2D_RL.py:49-127; 13 layers per actor, 21 per
+ * critic): out[b] = act(A[b] (X[b] W^T) + bias) for a batch of small graphs, float32 throughout.  Evaluated as ((A X) W^T): the
+ * neighbourhood sum is applied to the input rows on their way into LDS, the product with W^T runs on MFMA (v_mfma_f32_32x32x2_f32,
+ * float32 accumulation), bias / activation / accumulation are the epilogue -- H = X W never exists in HBM.  Same value as the
+ * reference's order of operations up to float32 rounding (<= 2e-5 relative against the float32 PyTorch layer in the tests).
+ *   x    [n_batch][n_nodes][k_in], rows x_row_stride floats apart (0 = k_in)
+ *   adj  dense [n_nodes][n_nodes] per graph (a_batch_stride = n_nodes^2) or one for all (0)
+ *   nbr  optional sparsity pattern as for truss_gcn_aggregate_sparse: int16 [n_nodes][k_nbr], -1 = unused, k_nbr <= 16;
+ *        NULL = dense, n_nodes <= 64 (the Pareto graph)
+ *   w    [c_out][k_in], k contiguous (the layout of torch.nn.Linear.weight), c_out <= 224; bias [c_out] or NULL
+ *   out  [n_batch][n_nodes][c_out], rows out_row_stride floats apart (0 = c_out); must not alias x
+ *   act  0 none, 1 relu, 2 sigmoid;  accumulate != 0: out += act(...) (the sum of the five second-level layers of the actor)
+ * n_nodes <= 256.  Device pointers. */
+typedef struct truss_gcn_layer_args {
+  size_t struct_size;
+  int32_t n_batch, n_nodes, k_in, c_out, act, accumulate, k_nbr, reserved;
+  const float *x;
+  int64_t x_row_stride;
+  const float *adj;
+  int64_t a_batch_stride;
+  const int16_t *nbr;
+  const float *w;
+  const float *bias;
+  float *out;
+  int64_t out_row_stride;
+  const uint16_t *w_bf16x3; /* NULL: the product runs on the float32 matrix cores.  Otherwise: `w` split into three bfloat16 terms by
+                               truss_gcn_split_w ([3][224][kp], kp = k_in rounded up to 16); the product then runs on the bf16
+                               matrix cores as six partial products with float32 accumulation ("bf16x3": every float32 operand is
+                               split EXACTLY into three bf16 terms, the three dropped cross terms are below 2^-24 |a||b|) -- 2.7 x
+                               fewer matrix-core cycles at float32 accuracy.  Hidden layers only: c_out 33..224, k_in % 4 == 0, x
+                               16-byte aligned, <= 9 terms per row; other shapes are refused with this pointer set. */
+} truss_gcn_layer_args_t;
+
+int truss_gcn_layer(const truss_gcn_layer_args_t *args, void *stream);
+
+/* w [c_out <= 224][k_in] float32 -> w_bf16x3 [3][224][kp] bfloat16 bit patterns (kp = (k_in + 15) & ~15; rows >= c_out and columns >=
+ * k_in are written as zeros: the layer kernel reads whole 224 x 16 slabs by LDS-DMA): the exact
+ * three-term split the bf16x3 path of truss_gcn_layer reads.  Once per weight version; device pointers, 16-byte aligned output. */
+int truss_gcn_split_w(const float *w, int32_t c_out, int32_t k_in, uint16_t *w_bf16x3, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -621,6 +621,8 @@ extern "C" int truss_debug_stamps(unsigned long long *out16) {
 }
 #endif
 
+#include "truss_gcn.h"
+
 #include "truss_front.h"
 extern "C" int truss_front(const truss_front_args_t *a, void *stream) {
   if (int rc = tb_front_check(a)) return rc;

@@ -1,6 +1,6 @@
 // truss_torch_ops.cpp -- PyTorch custom operators in front of the C ABI of include/truss_mi355.h.
 //
-//   torch.ops.truss_mi355.step / rollout / obs / front / gcn_aggregate / gcn_aggregate_sparse
+//   torch.ops.truss_mi355.step / rollout / obs / front / gcn_aggregate / gcn_aggregate_sparse / gcn_layer
 //
 // The reference's hot path runs inside TensorFlow ops on its side of the loop (truss2D_RL.py:328-354); here the env
 // step itself is an operator of the host framework: tensors in, tensors mutated in place, launched on the stream the
@@ -27,6 +27,8 @@ struct Backend {
   int (*gcn)(const float *, int64_t, const float *, const float *, float *, int32_t, int32_t, int32_t, int32_t, void *) = nullptr;
   int (*gcn_sparse)(const float *, int64_t, const int16_t *, int32_t, const float *, const float *, float *, int32_t, int32_t, int32_t,
                     int32_t, void *) = nullptr;
+  int (*gcn_layer)(const truss_gcn_layer_args_t *, void *) = nullptr;
+  int (*gcn_split)(const float *, int32_t, int32_t, uint16_t *, void *) = nullptr;
   const char *(*last_error)(void) = nullptr;
   bool device = false;   // true: the HIP library (tensors must be on a cuda device)
 };
@@ -235,11 +237,57 @@ void gcn_aggregate_sparse(int64_t lib, int64_t stream, const at::Tensor &adj, co
 }
 void gcn_sparse_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &, const at::Tensor &, const OT &, const at::Tensor &, int64_t) {}
 
+// one whole GCN layer, out = act(adj @ (x @ w^T) + bias) [+ out], on the matrix cores == truss_gcn_layer
+void gcn_layer(int64_t lib, int64_t stream, const at::Tensor &x, const at::Tensor &adj, const OT &nbr, const at::Tensor &w, const OT &bias,
+               const at::Tensor &out, int64_t act, bool accumulate, const OT &w_split) {
+  const Backend &b = backend(lib);
+  TORCH_CHECK(b.gcn_layer, "truss_mi355: the bound native library has no truss_gcn_layer");
+  TORCH_CHECK(x.dim() == 3 && out.dim() == 3 && w.dim() == 2, "truss_mi355: x [B, N, K], w [C, K], out [B, N, C]");
+  const int64_t B = x.size(0), N = x.size(1), K = x.size(2), C = w.size(0);
+  TORCH_CHECK(w.size(1) == K && out.size(0) == B && out.size(1) == N && out.size(2) == C, "truss_mi355: gcn_layer shapes do not match");
+  TORCH_CHECK((adj.dim() == 2 || adj.dim() == 3) && adj.size(-1) == N && adj.size(-2) == N && (adj.dim() == 2 || adj.size(0) == B),
+              "truss_mi355: adj must be [N, N] or [B, N, N]");
+  truss_gcn_layer_args_t a{};
+  a.struct_size = sizeof a;
+  a.n_batch = (int32_t)B;
+  a.n_nodes = (int32_t)N;
+  a.k_in = (int32_t)K;
+  a.c_out = (int32_t)C;
+  a.act = (int32_t)act;
+  a.accumulate = accumulate ? 1 : 0;
+  a.x = ptr<const float>(b, x, at::kFloat, "x");
+  a.adj = ptr<const float>(b, adj, at::kFloat, "adj");
+  a.a_batch_stride = adj.dim() == 3 ? N * N : 0;
+  if (nbr.has_value() && nbr->defined()) {
+    TORCH_CHECK(nbr->dim() == 2 && nbr->size(0) == N, "truss_mi355: nbr must be [N, K]");
+    a.nbr = ptr<const int16_t>(b, *nbr, at::kShort, "nbr");
+    a.k_nbr = (int32_t)nbr->size(1);
+  }
+  a.w = ptr<const float>(b, w, at::kFloat, "w");
+  a.bias = ptr<const float>(b, bias, at::kFloat, "bias", C);
+  a.out = ptr<float>(b, out, at::kFloat, "out");
+  a.w_bf16x3 = (const uint16_t *)ptr<const int16_t>(b, w_split, at::kShort, "w_split", 3 * 224 * ((K + 15) / 16 * 16));
+  check_rc(b, b.gcn_layer(&a, (void *)stream), "truss_gcn_layer");
+}
+void gcn_layer_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &, const OT &, const at::Tensor &, const OT &, const at::Tensor &,
+                    int64_t, bool, const OT &) {}
+
+// w [C, K] float32 -> out [3, 224, KP] int16 (bfloat16 bit patterns, zero rows / columns beyond C / K): the exact three-term split of the bf16x3 path == truss_gcn_split_w
+void gcn_split_w(int64_t lib, int64_t stream, const at::Tensor &w, const at::Tensor &out) {
+  const Backend &b = backend(lib);
+  TORCH_CHECK(b.gcn_split, "truss_mi355: the bound native library has no truss_gcn_split_w");
+  TORCH_CHECK(w.dim() == 2 && out.dim() == 3 && out.size(0) == 3 && out.size(1) == 224 && w.size(0) <= 224 && out.size(2) == (w.size(1) + 15) / 16 * 16,
+              "truss_mi355: gcn_split_w: w [C <= 224, K], out [3, 224, (K + 15) / 16 * 16]");
+  check_rc(b, b.gcn_split(ptr<const float>(b, w, at::kFloat, "w"), (int32_t)w.size(0), (int32_t)w.size(1),
+                          (uint16_t *)ptr<int16_t>(b, out, at::kShort, "out"), (void *)stream), "truss_gcn_split_w");
+}
+void gcn_split_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &) {}
+
 }  // namespace
 
 // Bind the entry points of a loaded native library (addresses from ctypes) under a small index.
 extern "C" int truss_torch_bind(int lib, void *step_fn, void *rollout_fn, void *obs_fn, void *front_fn, void *gcn_fn, void *gcn_sparse_fn,
-                                void *last_error_fn, int is_device) {
+                                void *gcn_layer_fn, void *gcn_split_fn, void *last_error_fn, int is_device) {
   if (lib < 0 || lib >= (int)g_backends.size() || !step_fn) return -1;
   Backend &b = g_backends[lib];
   b.step = (decltype(b.step))step_fn;
@@ -248,6 +296,8 @@ extern "C" int truss_torch_bind(int lib, void *step_fn, void *rollout_fn, void *
   b.front = (decltype(b.front))front_fn;
   b.gcn = (decltype(b.gcn))gcn_fn;
   b.gcn_sparse = (decltype(b.gcn_sparse))gcn_sparse_fn;
+  b.gcn_layer = (decltype(b.gcn_layer))gcn_layer_fn;
+  b.gcn_split = (decltype(b.gcn_split))gcn_split_fn;
   b.last_error = (decltype(b.last_error))last_error_fn;
   b.device = is_device != 0;
   return 0;
@@ -271,6 +321,9 @@ TORCH_LIBRARY(truss_mi355, m) {
         "Tensor(a!)? front_idx, Tensor(b!)? n_front, Tensor(c!)? hv_front, Tensor(d!)? hv_all, Tensor(e!)? metrics) -> ()");
   m.def("gcn_aggregate(int lib, int stream, Tensor adj, Tensor h, Tensor? bias, Tensor(a!) out, int act) -> ()");
   m.def("gcn_aggregate_sparse(int lib, int stream, Tensor adj, Tensor nbr, Tensor h, Tensor? bias, Tensor(a!) out, int act) -> ()");
+  m.def("gcn_layer(int lib, int stream, Tensor x, Tensor adj, Tensor? nbr, Tensor w, Tensor? bias, Tensor(a!) out, int act, bool accumulate, "
+        "Tensor? w_split) -> ()");
+  m.def("gcn_split_w(int lib, int stream, Tensor w, Tensor(a!) out) -> ()");
 }
 TORCH_LIBRARY_IMPL(truss_mi355, CPU, m) {   // the emulator library of the test-suite binds here
   m.impl("step", step);
@@ -279,6 +332,8 @@ TORCH_LIBRARY_IMPL(truss_mi355, CPU, m) {   // the emulator library of the test-
   m.impl("front", front);
   m.impl("gcn_aggregate", gcn_aggregate);
   m.impl("gcn_aggregate_sparse", gcn_aggregate_sparse);
+  m.impl("gcn_layer", gcn_layer);
+  m.impl("gcn_split_w", gcn_split_w);
 }
 TORCH_LIBRARY_IMPL(truss_mi355, CUDA, m) {  // = HIP on ROCm: the product library
   m.impl("step", step);
@@ -287,6 +342,8 @@ TORCH_LIBRARY_IMPL(truss_mi355, CUDA, m) {  // = HIP on ROCm: the product librar
   m.impl("front", front);
   m.impl("gcn_aggregate", gcn_aggregate);
   m.impl("gcn_aggregate_sparse", gcn_aggregate_sparse);
+  m.impl("gcn_layer", gcn_layer);
+  m.impl("gcn_split_w", gcn_split_w);
 }
 TORCH_LIBRARY_IMPL(truss_mi355, Meta, m) {  // tracing: every operator only mutates its outputs
   m.impl("step", step_meta);
@@ -295,4 +352,6 @@ TORCH_LIBRARY_IMPL(truss_mi355, Meta, m) {  // tracing: every operator only muta
   m.impl("front", front_meta);
   m.impl("gcn_aggregate", gcn_meta);
   m.impl("gcn_aggregate_sparse", gcn_sparse_meta);
+  m.impl("gcn_layer", gcn_layer_meta);
+  m.impl("gcn_split_w", gcn_split_meta);
 }

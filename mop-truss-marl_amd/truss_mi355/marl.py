@@ -122,59 +122,104 @@ def gcn_aggregate(lib, adj, h, bias, act, nbr=None):
     return out
 
 
-_HPAD = 224     # hidden width the inference GEMMs run at (see actor_infer)
-_pad_cache: dict = {}
+def split_weights(lib, w):
+    """w [C <= 224, K] float32 -> int16 [3, 224, KP] (bfloat16 bit patterns, zero padded): the exact three-term split the bf16x3 path
+    of the fused layer kernel reads (`truss_gcn_split_w`; one small launch).  `layer_split_weights` caches it per GCN layer."""
+    from . import ops
+    C, K = w.shape
+    out = torch.empty((3, 224, (K + 15) // 16 * 16), dtype=torch.int16, device=w.device)
+    ops.call(ops.namespace().gcn_split_w, ops.bind(lib), ops.stream_of(w.device), w, out)
+    return out
 
 
-def _padded_layer(layer, k_in):
-    """(weight [Cout_p, k_in], bias [Cout_p]) of a GCN layer for the padded inference path: hidden outputs (more than 16
-    channels) are widened to _HPAD with zero rows, inputs that are padded hidden activations get zero columns.  Rebuilt
-    when the layer's weights have changed (training updates them in place: tensor version counter)."""
-    w, bvec = layer.lin.weight, layer.bias
-    key = id(layer)
-    ver = (w._version, bvec._version, k_in, w.data_ptr())
-    hit = _pad_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1], hit[2]
-    cout, cin = w.shape
-    cp = _HPAD if 16 < cout <= _HPAD else cout
-    wp = torch.zeros((cp, k_in), dtype=w.dtype, device=w.device)
-    wp[:cout, :cin] = w.detach()
-    bp = torch.zeros((cp,), dtype=bvec.dtype, device=bvec.device)
-    bp[:cout] = bvec.detach()
-    _pad_cache[key] = (ver, wp, bp)
-    return wp, bp
+def layer_split_weights(lib, layer, k_pad=0):
+    """(w, split_weights(w)) of a truss2D_RL.GCNConv, kept on the module and redone when its kernel has changed (training updates the
+    weights in place: tensor version counter; load_state_dict / re-materialisation: data pointer).  k_pad > k_in: the kernel's input
+    columns are zero-padded to k_pad first (the 13-feature input layers run at 16 so that they take the 16-byte loaders)."""
+    w = layer.lin.weight
+    tag = (w._version, w.data_ptr(), tuple(w.shape), k_pad)
+    hit = getattr(layer, "_truss_split", None)
+    if hit is None or hit[0] != tag:
+        wd = w.detach()
+        if k_pad > wd.shape[1]:
+            wd = torch.nn.functional.pad(wd, (0, k_pad - wd.shape[1])).contiguous()
+        hit = (tag, wd, split_weights(lib, wd) if (wd.shape[0] > 32 and wd.shape[1] % 4 == 0) else None)
+        layer._truss_split = hit
+    return hit[1], hit[2]
+
+
+def gcn_layer(lib, x, adj, w, bias, act, nbr=None, out=None, accumulate=False, precision="bf16x3", w_split=None):
+    """One whole GCN layer through the hand-written MFMA kernel (`truss_gcn_layer`, csrc/truss_gcn.h):
+    out = act(adj @ (x @ w.T) + bias), or out += ... with `accumulate`; float32 in and out, inference (no autograd).
+    x [B,N,K] contiguous; adj [N,N] (shared) or [B,N,N]; w [C,K] = nn.Linear.weight, C <= 224; nbr: int16 [N,Kn] sparsity pattern of
+    adj (TrussTopology.neighbor_table(), Kn <= 16) or None for a dense adjacency of at most 64 nodes; N <= 256.
+    precision "bf16x3" (default): where the shape allows (the hidden layers: C > 32, K % 4 == 0, <= 9 terms per row) the product runs
+    on the bf16 matrix cores as six partial products of exactly split operands with float32 accumulation -- float32 accuracy, 2.7 x
+    fewer matrix-core cycles; "f32": always the float32 matrix cores.  w_split: split_weights(lib, w) if the caller keeps it."""
+    from . import ops
+    B, N, K = x.shape
+    C = w.shape[0]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    adj = adj.contiguous()
+    if adj.dim() == 3 and adj.shape[0] == 1:
+        adj = adj[0]
+    code = {None: 0, "relu": 1, "sigmoid": 2}[act]
+    ws = None
+    if precision == "bf16x3" and C > 32 and K % 4 == 0 and x.data_ptr() % 16 == 0 and (nbr.shape[1] if nbr is not None else N) <= 9:
+        ws = w_split if w_split is not None else split_weights(lib, w)
+    ops.call(ops.namespace().gcn_layer, ops.bind(lib), ops.stream_of(x.device), x, adj, nbr, w, bias, out, code, bool(accumulate), ws)
+    return out
+
+
+def gcn_layer_supported(n_nodes, c_out, nbr):
+    """shapes the fused layer kernel takes (include/truss_mi355.h); anything else goes through library GEMM + aggregation kernels"""
+    return c_out <= 224 and n_nodes <= 256 and ((nbr is not None and nbr.shape[1] <= 16) or (nbr is None and n_nodes <= 64))
 
 
 def actor_infer(lib, actor, ins, nbr=None):
-    """truss2D_RL.multimodes_actor.forward (truss2D_RL.py:49-120) for inference: the dense half of every
-    GCN layer (X W) stays a library GEMM over the whole batch, the neighbourhood aggregation + bias +
-    activation is one fused kernel per layer instead of a batched 16x16 GEMM and two elementwise passes.
-
-    The hidden width is 200; for M ~ 1e5 rows the library's heuristic gives N = 200 a 16 x 256 tile (195 us, 40 TFLOP/s)
-    and N = 224 a proper one (99 us) -- so the hidden activations are carried at 224 channels, the 24 extra ones being
-    exact zeros end to end (zero weight rows, zero bias, relu(0) = 0; zero weight columns in the consuming layer).
-    Same values up to the summation order of the GEMM.
-    nbr: the truss's neighbour table on the device (see gcn_aggregate) for the layers over the node graph."""
+    """truss2D_RL.multimodes_actor.forward (truss2D_RL.py:49-120) for inference, every GCN layer ONE launch of the fused MFMA
+    kernel (`gcn_layer`: neighbourhood sum on the input rows, product with W^T on the matrix cores, bias + activation in the
+    epilogue; H = X W never exists in HBM); the five second-level layers accumulate their sum x3 in place.  Same values as the
+    module up to float32 summation order ((A X) W instead of A (X W)).
+    nbr: the truss's neighbour table on the device (TrussTopology.neighbor_table()) for the layers over the node graph; the layer
+    over the Pareto graph (x_p, A_p) is dense.  Shapes outside the kernel's envelope (a node graph without pattern above 64 nodes)
+    fall back to library GEMM + `gcn_aggregate`."""
     x_n, A_n, A_s, A_ts, A_cs, x_p, A_p = ins
 
-    hid = actor.gcn_l1_1.lin.out_features                         # true hidden width (200)
-
-    def g(layer, x, a, act="relu"):
-        if isinstance(layer.lin.weight, torch.nn.parameter.UninitializedParameter):   # lazy layers: let the module materialise itself once,
-            k_true = hid if (x.shape[-1] == _HPAD and hid < _HPAD) else x.shape[-1]   # on the un-padded width of its input
+    def g(layer, x, a, act="relu", out=None, accumulate=False):
+        if isinstance(layer.lin.weight, torch.nn.parameter.UninitializedParameter):   # lazy layers: let the module materialise itself once
             with torch.no_grad():
-                layer(x[:1, :, :k_true], a[:1] if a.dim() == 3 else a)
-        wp, bp = _padded_layer(layer, x.shape[-1])
-        return gcn_aggregate(lib, a, torch.nn.functional.linear(x, wp).contiguous(), bp, act, None if a is A_p else nbr)
+                layer(x[:1], a[:1] if a.dim() == 3 else a)
+        w, bvec = layer.lin.weight, layer.bias
+        pat = None if a is A_p else nbr
+        x = x.contiguous()
+        if gcn_layer_supported(x.shape[1], w.shape[0], pat):
+            wd, ws = layer_split_weights(lib, layer, x.shape[2])     # (x_n arrives zero-padded to 16 features)
+            return gcn_layer(lib, x, a, wd, bvec.detach(), act, pat, out, accumulate, w_split=ws)
+        h = gcn_aggregate(lib, a, torch.nn.functional.linear(x, w).contiguous(), bvec, act, pat)
+        if out is None:
+            return h
+        return out.add_(h) if accumulate else out.copy_(h)
 
     a = actor
+    if x_n.shape[2] % 4 and gcn_layer_supported(x_n.shape[1], 200, nbr):
+        # 13 node features -> 16 (zero columns, matched by zero columns of the three input kernels): 16-byte loads, bf16x3 product
+        for layer in (a.gcn_l1_1, a.gcn_l1_2, a.gcn_l1_3):
+            if isinstance(layer.lin.weight, torch.nn.parameter.UninitializedParameter):
+                with torch.no_grad():
+                    layer(x_n[:1], A_n[:1] if A_n.dim() == 3 else A_n)
+        x_n = torch.nn.functional.pad(x_n, (0, 4 - x_n.shape[2] % 4))
     x11, x12, x13 = g(a.gcn_l1_1, x_n, A_n), g(a.gcn_l1_2, x_n, A_n), g(a.gcn_l1_3, x_n, A_n)
-    x14 = g(a.gcn_l1_4, x_p, A_p).sum(dim=1)[:, :a.gcn_l1_4.lin.out_features]           # un-padded: the tiling below mixes
-    B, H = x14.shape                                                                     # channels and nodes
+    x14 = g(a.gcn_l1_4, x_p, A_p).sum(dim=1)                                             # GlobalSumPool over the Pareto graph
+    B, H = x14.shape
     x14 = x14.unsqueeze(-1).expand(B, H, x11.shape[1]).reshape(B, x11.shape[1], H)      # _tile_pool (:87-93)
-    x3 = (g(a.gcn_l2_1, x11, A_n) + g(a.gcn_l2_2, x12, A_ts) + g(a.gcn_l2_3, x12, A_cs) + g(a.gcn_l2_4, x13, A_s)
-          + g(a.gcn_l2_5, x14.contiguous(), A_n))
+    x3 = g(a.gcn_l2_1, x11, A_n)
+    g(a.gcn_l2_2, x12, A_ts, out=x3, accumulate=True)
+    g(a.gcn_l2_3, x12, A_cs, out=x3, accumulate=True)
+    g(a.gcn_l2_4, x13, A_s, out=x3, accumulate=True)
+    g(a.gcn_l2_5, x14.contiguous(), A_n, out=x3, accumulate=True)
     x31, x32 = g(a.gcn_l3_1, x3, A_n), g(a.gcn_l3_2, x3, A_s)
     return g(a.gcn_l4_1, x31, A_n, "sigmoid"), g(a.gcn_l4_2, x32, A_n, "sigmoid")
 

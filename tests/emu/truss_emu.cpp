@@ -377,3 +377,69 @@ extern "C" int truss_gcn_aggregate(const float *adj, int64_t a_batch_stride, con
   }
   return TRUSS_OK;
 }
+
+// truss_gcn_layer, CPU stand-in of the MFMA kernel (plain loops, the same operation order: aggregate the input rows, then the
+// product with W^T, then bias / activation / accumulation) -- lets the host-side plumbing of the actors run in the CPU tests
+extern "C" int truss_gcn_layer(const truss_gcn_layer_args_t *a, void *) {
+  if (!a || a->struct_size != sizeof(truss_gcn_layer_args_t)) return tb_fail(TRUSS_EINVAL, "truss_gcn_layer: bad argument block");
+  if (!a->x || !a->adj || !a->w || !a->out) return tb_fail(TRUSS_EINVAL, "truss_gcn_layer: a required pointer is NULL");
+  if (a->c_out > 224 || a->n_nodes > 256 || (a->nbr ? (a->k_nbr < 1 || a->k_nbr > 16) : a->n_nodes > 64))
+    return tb_fail(TRUSS_EUNSUPPORTED, "truss_gcn_layer: shape outside the kernel's envelope");
+  const int N = a->n_nodes, K = a->k_in, C = a->c_out;
+  const long xs = a->x_row_stride ? a->x_row_stride : K, os = a->out_row_stride ? a->out_row_stride : C;
+  std::vector<float> xa((size_t)N * K);
+  for (int b = 0; b < a->n_batch; ++b) {
+    const float *A = a->adj + (size_t)b * a->a_batch_stride;
+    const float *X = a->x + (size_t)b * N * xs;
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < K; ++k) {
+        float acc = 0.0f;
+        if (a->nbr) {
+          for (int t = 0; t < a->k_nbr; ++t) {
+            const int j = a->nbr[i * a->k_nbr + t];
+            if (j >= 0) acc += A[(size_t)i * N + j] * X[(size_t)j * xs + k];
+          }
+        } else {
+          for (int j = 0; j < N; ++j) acc += A[(size_t)i * N + j] * X[(size_t)j * xs + k];
+        }
+        xa[(size_t)i * K + k] = acc;
+      }
+    for (int i = 0; i < N; ++i)
+      for (int c = 0; c < C; ++c) {
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc += xa[(size_t)i * K + k] * a->w[(size_t)c * K + k];
+        acc += a->bias ? a->bias[c] : 0.0f;
+        if (a->act == 1) acc = acc > 0.0f ? acc : 0.0f;
+        else if (a->act == 2) acc = 1.0f / (1.0f + expf(-acc));
+        float *o = a->out + ((size_t)b * N + i) * os + c;
+        *o = a->accumulate ? *o + acc : acc;
+      }
+  }
+  return TRUSS_OK;
+}
+
+// the exact three-term bfloat16 split of the bf16x3 path (host restatement); the emulated layer itself sums in float32
+extern "C" int truss_gcn_split_w(const float *w, int32_t c_out, int32_t k_in, uint16_t *out, void *) {
+  if (!w || !out || c_out < 1 || k_in < 1 || c_out > 224) return tb_fail(TRUSS_EINVAL, "truss_gcn_split_w: bad argument");
+  const int KP = (k_in + 15) & ~15, CP = 224;
+  for (int c = 0; c < CP; ++c)
+    for (int k = 0; k < KP; ++k) {
+      const float x = (c < c_out && k < k_in) ? w[(size_t)c * k_in + k] : 0.0f;
+      uint32_t u, u0, u1, u2;
+      memcpy(&u, &x, 4);
+      u0 = u & 0xffff0000u;
+      float f0, r1, f1, r2;
+      memcpy(&f0, &u0, 4);
+      r1 = x - f0;
+      memcpy(&u1, &r1, 4);
+      u1 &= 0xffff0000u;
+      memcpy(&f1, &u1, 4);
+      r2 = r1 - f1;
+      memcpy(&u2, &r2, 4);
+      const size_t i = (size_t)c * KP + k;
+      out[i] = (uint16_t)(u0 >> 16);
+      out[(size_t)CP * KP + i] = (uint16_t)(u1 >> 16);
+      out[2 * (size_t)CP * KP + i] = (uint16_t)(u2 >> 16);
+    }
+  return TRUSS_OK;
+}

@@ -161,6 +161,69 @@ def _check_sparse_aggregate(lib, device):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
 
 
+def _check_gcn_layer(lib, device):
+    """truss_gcn_layer (the fused MFMA layer kernel: neighbourhood sum on the way in, X' W^T on the matrix cores, bias / activation /
+    accumulation in the epilogue) against the plain float32 PyTorch layer act(A @ (X @ W^T) + b), at every truss size class of
+    BASELINE configs (12 ... 256 nodes, sparsity pattern of the truss), on the dense Pareto graph, for the actors' layer shapes
+    (13 -> 200, 4 -> 200, 200 -> 200, 200 -> 2 / 3) and odd ones.  Tolerance 2e-5 relative to the layer's output scale: the kernel
+    sums in a different order ((A X) W, K in slabs of 16, two k per MFMA step)."""
+    torch.manual_seed(7)
+    f = {None: lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid}
+
+    def check(x, adj, w, bias, act, nbr, accumulate=False):
+        ref0 = f[act](torch.matmul(adj, torch.matmul(x, w.t())) + (bias if bias is not None else 0.0))
+        for precision in ("bf16x3", "f32"):          # the bf16 matrix cores with exactly split operands (hidden layers) / the fp32 ones
+            out, ref = None, ref0
+            if accumulate:
+                out = torch.randn_like(ref0)
+                ref = ref0 + out
+            got = marl.gcn_layer(lib, x, adj, w, bias, act, nbr, out, accumulate, precision=precision)
+            scale = max(1.0, float(ref.abs().max()))
+            torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5 * scale)
+
+    for nx, B in ((6, 21), (8, 17), (16, 9), (32, 5), (64, 3), (128, 2)):           # 12 / 16 / 32 / 64 / 128 / 256 nodes
+        topo = tm.TrussTopology.grid(nx)
+        N = topo.N
+        tab = topo.neighbor_table()
+        pat = np.zeros((N, N), bool)
+        for i in range(N):
+            pat[i, tab[i][tab[i] >= 0]] = True
+        nbr, patt = torch.tensor(tab, device=device), torch.tensor(pat, device=device)
+        A_n, _ = topo.normalized_adjacency()
+        shared, per_env = torch.tensor(A_n, device=device), torch.rand(B, N, N, device=device) * patt
+        for K, C, act in ((13, 200, "relu"), (200, 200, "relu"), (200, 2, "sigmoid"), (200, 3, "sigmoid"), (37, 70, None)):
+            x, w, bias = torch.randn(B, N, K, device=device), torch.randn(C, K, device=device) / K ** 0.5, torch.randn(C, device=device)
+            check(x, per_env, w, bias, act, nbr)
+            check(x, shared, w, bias if K != 37 else None, act, nbr, accumulate=(K == 200 and C == 200))
+    for P, B in ((20, 13), (50, 4), (64, 3), (7, 40)):                               # dense: the Pareto graph (20 train / 50 test copies)
+        adj = torch.softmax(torch.randn(B, P, P, device=device), dim=-1)
+        x, w, bias = torch.rand(B, P, 4, device=device), torch.randn(200, 4, device=device), torch.randn(200, device=device)
+        check(x, adj, w, bias, "relu", None)
+        check(torch.randn(B, P, 200, device=device), adj[0], torch.randn(200, 200, device=device) / 14.0, bias, None, None)
+    # the split itself: three bfloat16 terms whose sum is the float32 weight to 2^-23 of its magnitude, zero padding to [3, 224, KP]
+    w = torch.randn(200, 200, device=device) * torch.logspace(-6, 6, 200, device=device)[:, None]
+    ws = marl.split_weights(lib, w)
+    assert ws.shape == (3, 224, 208) and ws.dtype == torch.int16
+    terms = (ws.to(torch.int32) << 16).view(torch.float32)
+    back = terms[0].double() + terms[1].double() + terms[2].double()
+    assert float((back[:200, :200] - w.double()).abs().max() / w.abs().max()) < 2.0 ** -23
+    assert torch.all((back[:200, :200] - w.double()).abs() <= w.abs().double() * 2.0 ** -23 + 1e-45)
+    assert int(ws[:, 200:, :].abs().max()) == 0 and int(ws[:, :, 200:].abs().max()) == 0
+    with pytest.raises(tm.TrussError):                                               # outside the envelope: refused, never silently wrong
+        marl.gcn_layer(lib, torch.zeros(1, 80, 8, device=device), torch.zeros(80, 80, device=device), torch.zeros(8, 8, device=device), None, None)
+    with pytest.raises(tm.TrussError):
+        marl.gcn_layer(lib, torch.zeros(1, 8, 8, device=device), torch.zeros(8, 8, device=device), torch.zeros(230, 8, device=device), None, None)
+
+
+def test_gcn_layer_emulated():
+    _check_gcn_layer(pc.emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_gcn_layer_hip():
+    _check_gcn_layer(tm.load(), "cuda")
+
+
 def test_sparse_aggregate_emulated():
     _check_sparse_aggregate(pc.emu_lib(), "cpu")
 
