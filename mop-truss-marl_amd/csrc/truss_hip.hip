@@ -84,6 +84,11 @@ __device__ __forceinline__ float tb_rcpf(float d) {
   return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
 
+#ifdef TRUSS_STOP_AT
+// Diagnostic build only (tools/lds_by_phase.sh): the step kernel returns at phase boundary TRUSS_STOP_AT (a TRUSS_ST index of the
+// schedule), so that PMC counters of builds with increasing boundaries give per-phase differences.  Results are wrong by construction.
+#define TRUSS_ST(i) do { if ((i) == TRUSS_STOP_AT) return; } while (0)
+#endif
 #ifdef TRUSS_STAMPS
 // Diagnostic build only (make diag): lane 0 of one mid-grid workgroup records s_memtime at the phase
 // boundaries into a buffer nothing else reads.  Never enabled in libtruss_mi355.so.
