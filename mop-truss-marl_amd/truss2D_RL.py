@@ -133,6 +133,97 @@ class multimodes_critic(nn.Module):
         return self.dense_out(q)
 
 
+# ---- level-wise ("grouped") evaluation of the networks for the MADDPG update -----------------------------------------------
+# At batch 32 a GCN layer is four small launches forward (X W, A H, + b, activation) and about seven backward, and a critic has 21 of
+# them although it is only two levels deep: the update is bound by its kernel count (2 312 launches, 9.5 ms as a replayed hipGraph).
+# The layers of one level do not depend on each other, so they are evaluated TOGETHER: the products X_i W_i of a level as one batched
+# GEMM over the stacked operands, the neighbourhood sums as one batched GEMM with bias (baddbmm) over the stacked adjacencies -- or,
+# where the layers share one adjacency, over the layers' outputs laid side by side along the channels -- and one activation.  Same
+# parameters (the modules' own tensors: state_dict, checkpoints and the per-layer `forward` are untouched), same mathematics; the
+# GEMMs sum in a different order (tests/test_master_rl.py::test_grouped_forward_matches_layerwise: outputs <= 1e-5, gradients <= 1e-4
+# of their scale).
+
+def _ready(layers):
+    return not any(isinstance(L.lin.weight, nn.parameter.UninitializedParameter) for L in layers)
+
+
+def _level_shared_adj(layers, xs, adj, act="relu"):
+    """layers[i](xs[i], adj) for all i, one adjacency [B,N,N]: outputs side by side, [B, N, n, C]."""
+    n, C = len(layers), layers[0].lin.out_features
+    if all(x is xs[0] for x in xs):                       # one input too: a single wide GEMM
+        h = nn.functional.linear(xs[0], torch.cat([L.lin.weight for L in layers], dim=0))            # [B,N,n*C]
+    elif len({x.shape[-1] for x in xs}) == 1:
+        B, N, K = xs[0].shape
+        h = torch.bmm(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]).transpose(1, 2))
+        h = h.reshape(n, B, N, C).permute(1, 2, 0, 3).reshape(B, N, n * C)
+    else:
+        h = torch.cat([nn.functional.linear(x, L.lin.weight) for L, x in zip(layers, xs)], dim=-1)
+    B, N = h.shape[0], h.shape[1]
+    bias = torch.cat([L.bias for L in layers])
+    out = torch.baddbmm(bias.expand(B, N, n * C), adj.expand(B, N, N), h)
+    out = torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
+    return out.reshape(B, N, n, C)
+
+
+def _level_own_adj(layers, xs, adjs, act="relu"):
+    """layers[i](xs[i], adjs[i]) for all i (same shapes): [n, B, N, C]."""
+    n, C = len(layers), layers[0].lin.out_features
+    B, N, K = xs[0].shape
+    h = torch.bmm(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]).transpose(1, 2))   # [n, B*N, C]
+    a = torch.stack([a_.expand(B, N, N) for a_ in adjs]).reshape(n * B, N, N)
+    bias = torch.stack([L.bias for L in layers])[:, None, None, :].expand(n, B, N, C).reshape(n * B, N, C)
+    out = torch.baddbmm(bias, a, h.reshape(n * B, N, C))
+    out = torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
+    return out.reshape(n, B, N, C)
+
+
+def actor_forward_grouped(actor, inputs):
+    """multimodes_actor.forward, level by level (see above)."""
+    a = actor
+    x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p = inputs
+    layers = [a.gcn_l1_1, a.gcn_l1_2, a.gcn_l1_3, a.gcn_l1_4, a.gcn_l2_1, a.gcn_l2_2, a.gcn_l2_3, a.gcn_l2_4, a.gcn_l2_5, a.gcn_l3_1,
+              a.gcn_l3_2, a.gcn_l4_1, a.gcn_l4_2]
+    if not _ready(layers):
+        return a(inputs)                                   # first call: let the lazy kernels materialise (Glorot) layer by layer
+    l1 = _level_shared_adj([a.gcn_l1_1, a.gcn_l1_2, a.gcn_l1_3], [x_n, x_n, x_n], A_n)              # [B,N,3,H]
+    x_1_1, x_1_2, x_1_3 = l1[:, :, 0], l1[:, :, 1], l1[:, :, 2]
+    x_1_4 = _tile_pool(a.gcn_l1_4(x_p, A_p, "relu").sum(dim=1), x_n.shape[1])
+    l2 = _level_own_adj([a.gcn_l2_1, a.gcn_l2_2, a.gcn_l2_3, a.gcn_l2_4, a.gcn_l2_5], [x_1_1, x_1_2, x_1_2, x_1_3, x_1_4],
+                        [A_n, A_n_ts, A_n_cs, A_s, A_n])
+    x_3 = l2.sum(dim=0)
+    l3 = _level_own_adj([a.gcn_l3_1, a.gcn_l3_2], [x_3, x_3], [A_n, A_s])
+    return a.gcn_l4_1(l3[0], A_n, "sigmoid"), a.gcn_l4_2(l3[1], A_n, "sigmoid")
+
+
+def critic_forward_grouped(critic, inputs):
+    """multimodes_critic.forward, level by level (see above)."""
+    c = critic
+    x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p, self_g, self_t, other_g1, other_t1, other_g2, other_t2 = inputs
+    if not _ready(list(c.l1) + list(c.l2)) or isinstance(c.dense_1.weight, nn.parameter.UninitializedParameter):
+        return c(inputs)
+    acts = [self_g, self_t, other_g1, other_t1, other_g2, other_t2]
+    # level 1 over the node graph: the three layers on x_n and the six on the actions share A_n -> nine outputs side by side
+    h_n = nn.functional.linear(x_n, torch.cat([c.l1[0].lin.weight, c.l1[1].lin.weight, c.l1[2].lin.weight], dim=0))
+    h_a = [nn.functional.linear(a_, c.l1[4 + i].lin.weight) for i, a_ in enumerate(acts)]
+    h = torch.cat([h_n] + h_a, dim=-1)                                                               # [B,N,9*H]
+    B, N = h.shape[0], h.shape[1]
+    H = c.l1[0].lin.out_features
+    bias = torch.cat([c.l1[i].bias for i in (0, 1, 2, 4, 5, 6, 7, 8, 9)])
+    l1 = torch.relu(torch.baddbmm(bias.expand(B, N, 9 * H), A_n.expand(B, N, N), h)).reshape(B, N, 9, H)
+    x_1_1, x_1_2, x_1_3 = l1[:, :, 0], l1[:, :, 1], l1[:, :, 2]
+    x_1_a = [l1[:, :, 3 + i] for i in range(6)]
+    x_1_4 = _tile_pool(c.l1[3](x_p, A_p, "relu").sum(dim=1), N)
+    # level 2: eleven layers, each with its own input; adjacencies A_n, A_n_ts, A_n_cs, A_s, A_n x 6, A_n
+    xs = [x_1_1, x_1_2, x_1_2, x_1_3] + x_1_a + [x_1_4]
+    adjs = [A_n, A_n_ts, A_n_cs, A_s] + [A_n] * 7
+    l2 = _level_own_adj(list(c.l2), xs, adjs)                                                         # [11,B,N,H]
+    # 11 x GlobalSumPool -> Concatenate: [B, 11*H]
+    q = l2.sum(dim=2).permute(1, 0, 2).reshape(B, 11 * H)
+    q = torch.relu(c.dense_1(q))
+    q = torch.relu(c.dense_2(q))
+    return c.dense_out(q)
+
+
 _seg_cache: dict = {}
 
 
@@ -381,41 +472,55 @@ class MADDPG:
         flat = lambda order: [A[order[0]][0], A[order[0]][1], A[order[1]][0], A[order[1]][1], A[order[2]][0], A[order[2]][1]]
         orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]          # (self, other1, other2) per agent (:561-563)
         self._ensure_ready(S, flat(orders[0]))
+        # Independent network passes run side by side: inside a hipGraph capture (truss_mi355/marl.py) each goes to its own stream,
+        # forked from and joined back to the capturing stream, so that the replayed graph has parallel branches -- at batch 32 a
+        # network pass is a chain of ~100 kernels that each fill a few percent of the chip.  Eager runs (warm-up, CPU tests, the
+        # per-env reference loop) keep one stream: the same operations in the same order per network, hence the same numbers.
+        par = self._branches()
         with torch.no_grad():
             # the three next states (one per agent's move, :561-600) go through the target networks as ONE batch of
             # 3 x batch samples: 6 network passes instead of 18 (the update is bound by its kernel count)
             nb = NS[0][0].shape[0]
             NSc = [torch.cat([NS[f][k] for f in range(3)], dim=0) for k in range(len(NS[0]))]
-            na = [ag.target_actor_model(self._actor_in(NSc)) for ag in self.agents]
-            q_next = [[None] * 3 for _ in range(3)]
-            for i, ag in enumerate(self.agents):
-                o = orders[i]
-                q = ag.target_critic_model(NSc + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1], na[o[2]][0], na[o[2]][1]])
-                for f in range(3):
-                    q_next[f][i] = q[f * nb:(f + 1) * nb]
+            na = par([lambda ag=ag: actor_forward_grouped(ag.target_actor_model, self._actor_in(NSc)) for ag in self.agents])
+            tq = par([lambda ag=ag, o=orders[i]: critic_forward_grouped(
+                ag.target_critic_model, NSc + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1], na[o[2]][0], na[o[2]][1]])
+                for i, ag in enumerate(self.agents)])
+            q_next = [[tq[i][f * nb:(f + 1) * nb] for i in range(3)] for f in range(3)]
         # The three critic updates depend on nothing another network's update changes (replayed actions, target networks): they
         # come first -- exactly the reference's results, since critic i is not touched between its own step and agent i's actor
         # update (:603-629) -- and, data-parallel, their gradients travel as ONE flat buffer (one RCCL all-reduce for the three).
-        for i, ag in enumerate(self.agents):
+
+        def critic_grads(i, ag):
             o = orders[i]
             # TD target; `done` never fires in the reference (it compares an action array with `is 1`)
             y = R[:, i:i + 1] + self.gamma * (q_next[0][i] + q_next[1][i] + q_next[2][i]) / 3
             ag.critic_opt.zero_grad(set_to_none=True)
-            loss = torch.mean((ag.critic_model(S + flat(o)) - y) ** 2)
+            loss = torch.mean((critic_forward_grouped(ag.critic_model, S + flat(o)) - y) ** 2)
             loss.backward()
-            ag.c_loss.append(loss.detach())          # stays on the device: no synchronisation inside the update
+            return loss.detach()                     # stays on the device: no synchronisation inside the update
+
+        for ag, loss in zip(self.agents, par([lambda i=i, ag=ag: critic_grads(i, ag) for i, ag in enumerate(self.agents)])):
+            ag.c_loss.append(loss)
         cps = [list(ag.critic_model.parameters()) for ag in self.agents]
         _allreduce_grads(cps, self.dist)
         for ag, cp in zip(self.agents, cps):
             _clip_each(cp)
             ag.critic_opt.step()
         # The actor updates stay one after the other: agent i's loss re-evaluates ALL three actors (:617-629), i.e. it sees the
-        # weights agents < i have just stepped to -- one collective per actor.
+        # weights agents < i have just stepped to -- one collective per actor.  (The other two actors' passes carry no gradient
+        # that is asked for -- autograd.grad is taken with respect to agent i's parameters only -- so they run without a graph.)
         for i, ag in enumerate(self.agents):
             o = orders[i]
-            preds = [a2.actor_model(self._actor_in(S)) for a2 in self.agents]
-            q = ag.critic_model(S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
-                                     preds[o[2]][1]])
+
+            def other(a2):
+                with torch.no_grad():
+                    return actor_forward_grouped(a2.actor_model, self._actor_in(S))
+
+            preds = par([(lambda a2=a2: actor_forward_grouped(a2.actor_model, self._actor_in(S))) if a2 is ag else (lambda a2=a2: other(a2))
+                         for a2 in self.agents])
+            q = critic_forward_grouped(ag.critic_model, S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
+                                                             preds[o[2]][1]])
             actor_loss = -q.mean()
             ap = list(ag.actor_model.parameters())
             for p in ap:
@@ -426,6 +531,27 @@ class MADDPG:
             _allreduce_grads([ap], self.dist)
             _clip_each(ap)
             _fresh_adam_step(ap, ag.lr * 0.1, 1e-7)                                      # a fresh optimiser every call (:629)
+
+    def _branches(self):
+        """callable(list of thunks) -> list of results; on side streams when the current CUDA stream is being captured"""
+        dev = self.device
+        if dev.type != "cuda" or not torch.cuda.is_current_stream_capturing():
+            return lambda fns: [f() for f in fns]
+        if getattr(self, "_side_streams", None) is None:
+            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        streams = self._side_streams
+
+        def run(fns):
+            cur = torch.cuda.current_stream(dev)
+            outs = []
+            for st, f in zip(streams, fns):
+                st.wait_stream(cur)                  # fork: the branch sees everything enqueued so far
+                with torch.cuda.stream(st):
+                    outs.append(f())
+            for st in streams[:len(fns)]:
+                cur.wait_stream(st)                  # join
+            return outs
+        return run
 
     def sync_parameters(self, src=0):
         """Data-parallel start: every rank takes rank `src`'s actor / critic / target weights (one broadcast

@@ -249,3 +249,33 @@ def test_update_helpers_match_their_per_tensor_definitions():
         for p, q in zip(ps, qs):
             torch.testing.assert_close(q, p, rtol=2e-6, atol=1e-8)
     assert len(mine.state_tensors()) == 1 + 2 * len(qs) and float(mine.step_t) == 6.0
+
+
+def test_grouped_forward_matches_layerwise():
+    """The level-wise evaluation the MADDPG update uses (truss2D_RL.actor_forward_grouped / critic_forward_grouped: the layers of a
+    level as batched GEMMs over stacked operands) computes what the modules' own layer-by-layer forward computes: outputs to 1e-5,
+    gradients with respect to every parameter to 1e-4 of their scale; lazy kernels are still materialised by the first call."""
+    import truss2D_RL as RL
+    torch.manual_seed(3)
+    B, N, P, H = 6, 16, 20, 48
+    r = lambda *s: torch.rand(*s)
+    A = lambda n: torch.softmax(torch.randn(B, n, n), -1)
+    S = [r(B, N, 13), A(N)[:1].expand(B, -1, -1), A(N), A(N), A(N), torch.ones(B, N, N), r(B, P, 4), A(P)]
+    ain = [S[0], S[1], S[2], S[3], S[4], S[6], S[7]]
+    acts = [r(B, N, 2), r(B, N, 3), r(B, N, 2), r(B, N, 3), r(B, N, 2), r(B, N, 3)]
+    actor, critic = RL.multimodes_actor(H, 2, 3), RL.multimodes_critic(H, 24)
+    first = RL.actor_forward_grouped(actor, ain)           # lazy layers: the grouped entry materialises them through the module
+    assert not isinstance(actor.gcn_l2_3.lin.weight, torch.nn.parameter.UninitializedParameter)
+    RL.critic_forward_grouped(critic, S + acts)
+    for a, b in zip(RL.actor_forward_grouped(actor, ain), actor(ain)):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(first[0], actor(ain)[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(RL.critic_forward_grouped(critic, S + acts), critic(S + acts), rtol=1e-5, atol=1e-6)
+    loss_a = lambda o: o[0].sum() + o[1].pow(2).sum()
+    for net, fwd_g, fwd, loss in ((actor, lambda: RL.actor_forward_grouped(actor, ain), lambda: actor(ain), loss_a),
+                                  (critic, lambda: RL.critic_forward_grouped(critic, S + acts), lambda: critic(S + acts), lambda q: q.pow(2).mean())):
+        ps = list(net.parameters())
+        g1 = torch.autograd.grad(loss(fwd()), ps)
+        g2 = torch.autograd.grad(loss(fwd_g()), ps)
+        for a, b in zip(g1, g2):
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9

@@ -71,12 +71,11 @@ for name in ("bench_under_trace.json", "bench_plain.json"):
     except Exception as e:  # noqa: BLE001
         res[name[:-5]] = f"unavailable: {e}"
 src = open(os.path.join(root, "mop-truss-marl_amd", "csrc", "truss_body.h"), "rb").read()
-plain = [v for k, v in res["hbm_bytes_per_launch"].items() if "rollout_kernel" in k] or \
-        [v for k, v in res["hbm_bytes_per_launch"].items() if "false" in k]
-fused = [v for k, v in res["hbm_bytes_per_launch"].items() if "step_kernel" in k and "true" in k]
+pick = lambda test: next((v["total"] for k, v in res["hbm_bytes_per_launch"].items() if test(k)), None)
 json.dump({"envs": 4096, "nodes": 32, "elements": 80, "truss_body_sha16": hashlib.sha256(src).hexdigest()[:16],
-           "step_kernel_bytes_per_launch": plain[0]["total"] if plain else None,     # per STEP (persistent rollout: per launch / steps)
-           "fused_step_kernel_bytes_per_launch": fused[0]["total"] if fused else None,
+           "step_kernel_bytes_per_launch": pick(lambda k: "step_kernel" in k and "false" in k),      # one launch of truss_step_kernel
+           "rollout_kernel_bytes_per_step": pick(lambda k: "rollout_kernel" in k),                   # persistent rollout: per launch / steps
+           "fused_step_kernel_bytes_per_launch": pick(lambda k: "step_kernel" in k and "true" in k),
            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x 2 (gfx950), median over dispatches"},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
