@@ -240,7 +240,11 @@ __global__ __launch_bounds__(EMIT ? 128 : 64) void truss_step_kernel(const TopoD
 #else
 #define SST(i)
 #endif
-      ln.emit_tables_load(T);   // ahead of every store of this wave in the vmcnt order
+      ln.emit_tables_load(T);   // ahead of every store of this wave in the vmcnt order ...
+      __builtin_amdgcn_s_waitcnt(0);   // ... and waited for HERE, while this wave has nothing else to do: gfx9 counts loads and stores
+                                       // in one vmcnt, so a first use of a table register behind stores would wait for all of them
+                                       // (the compiler put s_waitcnt vmcnt(0) in front of the row tensors' gathers: segment 3 could
+                                       // not start before segment 2's 32 KB per workgroup had retired)
       bool ok = tb_await(smem, T.o_flag, 1);
       if (ok) {
         SST(20);

@@ -178,13 +178,24 @@ def gcn_layer_supported(n_nodes, c_out, nbr):
     return c_out <= 224 and n_nodes <= 256 and ((nbr is not None and nbr.shape[1] <= 16) or (nbr is None and n_nodes <= 64))
 
 
-def actor_infer(lib, actor, ins, nbr=None):
+def path_graph_table(n_nodes):
+    """int16 [P, 3] neighbour table of the Pareto graph: `pareto_graph` / truss2D_ENV.pareto_state_data build a PATH over the front's
+    members (self loops + consecutive members), so row i of A_p is zero outside columns i - 1, i, i + 1"""
+    t = np.full((n_nodes, 3), -1, np.int16)
+    for i in range(n_nodes):
+        t[i, 0] = i - 1 if i > 0 else -1
+        t[i, 1] = i
+        t[i, 2] = i + 1 if i + 1 < n_nodes else -1
+    return t
+
+
+def actor_infer(lib, actor, ins, nbr=None, nbr_p=None):
     """truss2D_RL.multimodes_actor.forward (truss2D_RL.py:49-120) for inference, every GCN layer ONE launch of the fused MFMA
     kernel (`gcn_layer`: neighbourhood sum on the input rows, product with W^T on the matrix cores, bias + activation in the
     epilogue; H = X W never exists in HBM); the five second-level layers accumulate their sum x3 in place.  Same values as the
     module up to float32 summation order ((A X) W instead of A (X W)).
-    nbr: the truss's neighbour table on the device (TrussTopology.neighbor_table()) for the layers over the node graph; the layer
-    over the Pareto graph (x_p, A_p) is dense.  Shapes outside the kernel's envelope (a node graph without pattern above 64 nodes)
+    nbr: the truss's neighbour table on the device (TrussTopology.neighbor_table()) for the layers over the node graph; nbr_p: the
+    same for the Pareto graph (path_graph_table(P) when A_p comes from `pareto_graph`; None = dense, at most 64 members).  Shapes outside the kernel's envelope (a node graph without pattern above 64 nodes)
     fall back to library GEMM + `gcn_aggregate`."""
     x_n, A_n, A_s, A_ts, A_cs, x_p, A_p = ins
 
@@ -193,7 +204,7 @@ def actor_infer(lib, actor, ins, nbr=None):
             with torch.no_grad():
                 layer(x[:1], a[:1] if a.dim() == 3 else a)
         w, bvec = layer.lin.weight, layer.bias
-        pat = None if a is A_p else nbr
+        pat = nbr_p if a is A_p else nbr
         x = x.contiguous()
         if gcn_layer_supported(x.shape[1], w.shape[0], pat):
             wd, ws = layer_split_weights(lib, layer, x.shape[2])     # (x_n arrives zero-padded to 16 features)
@@ -283,6 +294,7 @@ class BatchedMARL:
         self.A_n = torch.tensor(A_n, device=dev)[None]
         self.mask = torch.tensor(mask, device=dev)[None]
         self.nbr = torch.tensor(topo.neighbor_table(), device=dev)     # sparsity pattern of every node-graph adjacency (actor inference)
+        self.nbr_p = torch.tensor(path_graph_table(P), device=dev)     # ... and of the Pareto graph (a path over the front's members)
         self.pts = torch.zeros((B, P, 4), dtype=torch.float64, device=dev)
         self.arch_y = torch.zeros((B, P, N), dtype=torch.float32, device=dev)
         self.arch_sec = torch.zeros((B, P, E), dtype=torch.int32, device=dev)
@@ -369,7 +381,7 @@ class BatchedMARL:
         with torch.no_grad():
             for ag in self.rl.agents:
                 g, t = actor_infer(self.lib, ag.actor_model, [actor_in[0], self.A_n[0], actor_in[2], actor_in[3], actor_in[4],
-                                                              actor_in[5], actor_in[6]], nbr=self.nbr)
+                                                              actor_in[5], actor_in[6]], nbr=self.nbr, nbr_p=self.nbr_p)
                 if explore:                                           # truss2D_RL.OUNoise.gen_noise per scalar (:41-48), all columns at once
                     for out, noises in ((g, ag.noise_geo), (t, ag.noise_topo)):
                         th_dt, mu, sg = self._noise_vectors(noises)

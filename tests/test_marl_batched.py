@@ -110,6 +110,24 @@ def _check_actor_infer(lib, device):
     for a, b in zip(got, ref):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+    # the way the batched rollout calls it: the Pareto graph from `pareto_graph` (a path over the front's members) with its
+    # neighbour table, the node-graph adjacencies on the truss's pattern with theirs -- every layer takes the sparse / bf16x3 path
+    topo = tm.TrussTopology.grid(8)
+    tab = topo.neighbor_table()
+    pat = np.zeros((N, N), bool)
+    for i in range(N):
+        pat[i, tab[i][tab[i] >= 0]] = True
+    patt = torch.tensor(pat, device=device)
+    pts = torch.rand(B, P, 4, dtype=torch.float64, device=device)
+    nfr = torch.randint(1, P + 1, (B,), device=device)
+    x_p, A_p = marl.pareto_graph(pts, nfr, torch.zeros(B, dtype=torch.long, device=device), P)
+    A_n = torch.tensor(topo.normalized_adjacency()[0], device=device)
+    ins2 = [r(B, N, 13), A_n, r(B, N, N) * patt, r(B, N, N) * patt, r(B, N, N) * patt, x_p, A_p]
+    with torch.no_grad():
+        ref = actor([ins2[0], A_n[None].expand(B, -1, -1)] + ins2[2:])
+        got = marl.actor_infer(lib, actor, ins2, nbr=torch.tensor(tab, device=device), nbr_p=torch.tensor(marl.path_graph_table(P), device=device))
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
     h = r(B, 24, 70)                                   # odd sizes, per-env adjacency, every activation
     adj = A(24)
     bias = r(70)
