@@ -335,10 +335,6 @@ def main():
                  "frac_of_hbm_peak_B_obs": B * b_ref / (so_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                  "frac_of_hbm_peak_bytes_moved": B * b_wr / (so_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
-    configs = None
-    if on_gpu and not args.no_configs:
-        configs = run_configs(args, tm, lib, dev, dist, rank, world, args.configs_budget)
-
     extras = {}
     if args.extras and rank == 0 and on_gpu:
         import bench_extras
@@ -402,14 +398,35 @@ def main():
             "state_emitting_step": state,
             "nonpositive_pivots": st,
         }
-        if configs is not None:
-            out["configs"] = configs
         if strong:
             out["strong"] = strong
         if extras:
             out["extras"] = extras
         if cpu is not None:
             out["cpu_baseline"] = cpu
+    else:
+        out = None
+
+    # BASELINE configs[2]-[4], after the headline is complete: the line is printed in every case.  A watchdog on every rank ends the
+    # process cleanly if the block does not come back (a collective that never completes cannot be interrupted from Python): rank 0
+    # then prints the headline with the reason in `configs`.
+    if on_gpu and not args.no_configs:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["configs"] = {"error": f"did not finish within {args.configs_budget + 150:.0f} s; headline measurements above are complete"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        guard = threading.Timer(args.configs_budget + 150 + (0 if rank == 0 else 5), give_up)
+        guard.daemon = True
+        guard.start()
+        configs = run_configs(args, tm, lib, dev, dist, rank, world, args.configs_budget)
+        guard.cancel()
+        if rank == 0:
+            out["configs"] = configs
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -6,6 +6,7 @@ one design (one `_game_modify`, like the FEM-only metric); a game step of the ba
 per env."""
 import contextlib
 import io
+import os
 import time
 
 import numpy as np
@@ -110,6 +111,11 @@ def large_bridge(global_envs=8192, steps=3, train=True, nx=16, dev="cuda", dist=
     topo = tm.TrussTopology.grid(nx)
     torch.manual_seed(7)                                      # same initial weights everywhere (and broadcast once more by the engine)
     eng = marl.BatchedMARL(topo, B, _maddpg(dev, dist), max_front=20, device=dev, replay_capacity=32768, batch_size=32, seed=rank)
+    if world > 1 and os.environ.get("TRUSS_DP_GRAPH", "0") != "1":
+        # The update with its RCCL all-reduces captured into a hipGraph is tested with a one-rank group (tests/test_rccl_single_gpu.py);
+        # with several ranks it has never run on hardware, so the default there is the eager update (collectives outside any graph,
+        # the path the world-size-2 gloo tests cover).  TRUSS_DP_GRAPH=1 opts in.
+        eng.use_train_graph = False
     x = np.tile(np.arange(nx) * 5.0, 2)                       # test/02_large_bridge: 15 bays of 5 m, span_y 6, targets 3.0 ... 2.0 ... 3.0
     tar = np.concatenate([np.zeros(nx), 2.0 + np.abs(np.linspace(-1, 1, nx))])
     y0 = np.concatenate([np.zeros(nx), np.full(nx, 6.0)]).astype(np.float32)
