@@ -183,7 +183,12 @@ typedef __attribute__((address_space(3))) int tb_lds_word;
 __device__ __forceinline__ tb_lds_word *tb_flag_ptr(char *lds, int o_flag) { return (tb_lds_word *)(lds + o_flag); }
 __device__ __forceinline__ void tb_publish(char *lds, int o_flag, int k) {
   __builtin_amdgcn_wave_barrier();
+#ifdef TRUSS_FLAG_RELAXED   // A/B only (tools/experiments/README.md): rounds 1-2's reliance on the in-order LDS pipeline, without the release's lgkmcnt(0)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (threadIdx.x == 0) __hip_atomic_store(tb_flag_ptr(lds, o_flag), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
   if (threadIdx.x == 0) __hip_atomic_store(tb_flag_ptr(lds, o_flag), k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 // Bounded wait of the streaming wave for progress >= k.  false = gave up (the compute wave never got there -- it faulted or the
 // launch is being torn down); the caller then flags the env in status[] (TRUSS_STATUS_OBS_TIMEOUT) instead of streaming garbage.
