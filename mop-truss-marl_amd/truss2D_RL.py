@@ -497,7 +497,9 @@ class MADDPG:
             y = R[:, i:i + 1] + self.gamma * (q_next[0][i] + q_next[1][i] + q_next[2][i]) / 3
             ag.critic_opt.zero_grad(set_to_none=True)
             loss = torch.mean((critic_forward_grouped(ag.critic_model, S + flat(o)) - y) ** 2)
-            loss.backward()
+            loss.backward()      # (autograd.grad + `p.grad = g` would save backward()'s clone per parameter, but the gradients are then
+            #                       slices of the levels' stacked gradients and PyTorch's multi-tensor Adam falls back to one launch
+            #                       per tensor: 1 646 -> 1 991 launches when tried)
             return loss.detach()                     # stays on the device: no synchronisation inside the update
 
         for ag, loss in zip(self.agents, par([lambda i=i, ag=ag: critic_grads(i, ag) for i, ag in enumerate(self.agents)])):
@@ -510,15 +512,18 @@ class MADDPG:
         # The actor updates stay one after the other: agent i's loss re-evaluates ALL three actors (:617-629), i.e. it sees the
         # weights agents < i have just stepped to -- one collective per actor.  (The other two actors' passes carry no gradient
         # that is asked for -- autograd.grad is taken with respect to agent i's parameters only -- so they run without a graph.)
+        def no_grad_eval(a2):
+            with torch.no_grad():
+                return actor_forward_grouped(a2.actor_model, self._actor_in(S))
+
+        frozen = {}          # no-gradient evaluations that are still valid: actor j's weights only change in iteration j
         for i, ag in enumerate(self.agents):
             o = orders[i]
-
-            def other(a2):
-                with torch.no_grad():
-                    return actor_forward_grouped(a2.actor_model, self._actor_in(S))
-
-            preds = par([(lambda a2=a2: actor_forward_grouped(a2.actor_model, self._actor_in(S))) if a2 is ag else (lambda a2=a2: other(a2))
-                         for a2 in self.agents])
+            todo = [j for j in range(len(self.agents)) if j != i and j not in frozen]
+            res = par([(lambda: actor_forward_grouped(ag.actor_model, self._actor_in(S)))] + [lambda a2=self.agents[j]: no_grad_eval(a2) for j in todo])
+            for j, r_ in zip(todo, res[1:]):
+                frozen[j] = r_
+            preds = [res[0] if j == i else frozen[j] for j in range(len(self.agents))]
             q = critic_forward_grouped(ag.critic_model, S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
                                                              preds[o[2]][1]])
             actor_loss = -q.mean()
@@ -531,6 +536,9 @@ class MADDPG:
             _allreduce_grads([ap], self.dist)
             _clip_each(ap)
             _fresh_adam_step(ap, ag.lr * 0.1, 1e-7)                                      # a fresh optimiser every call (:629)
+            # agent i's weights have just changed: an evaluation of actor i taken before this step must not be reused (the others'
+            # stay valid: agents > i have not stepped yet, evaluations of agents < i were taken after their steps)
+            frozen = {j: v for j, v in frozen.items() if j != i}
 
     def _branches(self):
         """callable(list of thunks) -> list of results; on side streams when the current CUDA stream is being captured"""
