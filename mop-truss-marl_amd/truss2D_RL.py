@@ -143,6 +143,25 @@ class multimodes_critic(nn.Module):
 # GEMMs sum in a different order (tests/test_master_rl.py::test_grouped_forward_matches_layerwise: outputs <= 1e-5, gradients <= 1e-4
 # of their scale).
 
+class _LevelMM(torch.autograd.Function):
+    """H[i] = X[i] @ W[i]^T for the stacked inputs X [n, M, K] and the stacked kernels W [n, C, K] (nn.Linear layout).  torch.bmm
+    with the transposed stack does the same forward; its backward hands the kernels' gradient back as a TRANSPOSED view, the
+    per-layer slices are then not contiguous, and every multi-tensor step that follows (clip, Adam, the flat all-reduce buffer)
+    falls back to one launch per parameter tensor.  Here the gradient is produced in the kernels' own layout."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.bmm(x, w.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w = ctx.saved_tensors
+        dx = torch.bmm(dh, w) if ctx.needs_input_grad[0] else None
+        dw = torch.bmm(dh.transpose(1, 2), x) if ctx.needs_input_grad[1] else None       # [n, C, K], contiguous
+        return dx, dw
+
+
 def _ready(layers):
     return not any(isinstance(L.lin.weight, nn.parameter.UninitializedParameter) for L in layers)
 
@@ -154,7 +173,7 @@ def _level_shared_adj(layers, xs, adj, act="relu"):
         h = nn.functional.linear(xs[0], torch.cat([L.lin.weight for L in layers], dim=0))            # [B,N,n*C]
     elif len({x.shape[-1] for x in xs}) == 1:
         B, N, K = xs[0].shape
-        h = torch.bmm(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]).transpose(1, 2))
+        h = _LevelMM.apply(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]))
         h = h.reshape(n, B, N, C).permute(1, 2, 0, 3).reshape(B, N, n * C)
     else:
         h = torch.cat([nn.functional.linear(x, L.lin.weight) for L, x in zip(layers, xs)], dim=-1)
@@ -165,19 +184,43 @@ def _level_shared_adj(layers, xs, adj, act="relu"):
     return out.reshape(B, N, n, C)
 
 
-def _level_own_adj(layers, xs, adjs, act="relu"):
-    """layers[i](xs[i], adjs[i]) for all i (same shapes): [n, B, N, C]."""
+def _adj_stack(adjs, B, N, cache=None):
+    """the adjacencies of a level, stacked for the batched GEMM: [n * B, N, N]"""
+    key = (B,) + tuple(id(a_) for a_ in adjs)
+    a = None if cache is None else cache.get(key)
+    if a is None:
+        a = torch.stack([a_.expand(B, N, N) for a_ in adjs]).reshape(len(adjs) * B, N, N)
+        if cache is not None:
+            cache[key] = a
+            cache.setdefault("_keep", []).extend(adjs)        # the ids in the key stay unique while the cache lives
+    return a
+
+
+def _level_adjacencies(S):
+    """The three adjacency stacks the grouped passes over minibatch S = [x_n, A_n, A_s, A_n_ts, A_n_cs, ...] need (actor levels 2 and
+    3, critic level 2), built once, on the CALLER's stream: the passes of one update run on parallel streams and only read them."""
+    x_n, A_n, A_s, A_n_ts, A_n_cs = S[:5]
+    B, N = x_n.shape[0], x_n.shape[1]
+    cache = {}
+    for adjs in ([A_n, A_n_ts, A_n_cs, A_s, A_n], [A_n, A_s], [A_n, A_n_ts, A_n_cs, A_s] + [A_n] * 7):
+        _adj_stack(adjs, B, N, cache)
+    return cache
+
+
+def _level_own_adj(layers, xs, adjs, act="relu", cache=None):
+    """layers[i](xs[i], adjs[i]) for all i (same shapes): [n, B, N, C].  `cache`: a dict that lives for one update -- the stacked
+    adjacencies are data only, the same for every network evaluated on the same minibatch."""
     n, C = len(layers), layers[0].lin.out_features
     B, N, K = xs[0].shape
-    h = torch.bmm(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]).transpose(1, 2))   # [n, B*N, C]
-    a = torch.stack([a_.expand(B, N, N) for a_ in adjs]).reshape(n * B, N, N)
+    h = _LevelMM.apply(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]))              # [n, B*N, C]
+    a = _adj_stack(adjs, B, N, cache)
     bias = torch.stack([L.bias for L in layers])[:, None, None, :].expand(n, B, N, C).reshape(n * B, N, C)
     out = torch.baddbmm(bias, a, h.reshape(n * B, N, C))
     out = torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
     return out.reshape(n, B, N, C)
 
 
-def actor_forward_grouped(actor, inputs):
+def actor_forward_grouped(actor, inputs, cache=None):
     """multimodes_actor.forward, level by level (see above)."""
     a = actor
     x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p = inputs
@@ -186,16 +229,18 @@ def actor_forward_grouped(actor, inputs):
     if not _ready(layers):
         return a(inputs)                                   # first call: let the lazy kernels materialise (Glorot) layer by layer
     l1 = _level_shared_adj([a.gcn_l1_1, a.gcn_l1_2, a.gcn_l1_3], [x_n, x_n, x_n], A_n)              # [B,N,3,H]
-    x_1_1, x_1_2, x_1_3 = l1[:, :, 0], l1[:, :, 1], l1[:, :, 2]
+    # unbind, not l1[:, :, i]: its backward is ONE stack of the pieces' gradients; every select's backward is a fill, a copy and an
+    # add into the running sum
+    x_1_1, x_1_2, x_1_3 = l1.unbind(2)
     x_1_4 = _tile_pool(a.gcn_l1_4(x_p, A_p, "relu").sum(dim=1), x_n.shape[1])
     l2 = _level_own_adj([a.gcn_l2_1, a.gcn_l2_2, a.gcn_l2_3, a.gcn_l2_4, a.gcn_l2_5], [x_1_1, x_1_2, x_1_2, x_1_3, x_1_4],
-                        [A_n, A_n_ts, A_n_cs, A_s, A_n])
+                        [A_n, A_n_ts, A_n_cs, A_s, A_n], cache=cache)
     x_3 = l2.sum(dim=0)
-    l3 = _level_own_adj([a.gcn_l3_1, a.gcn_l3_2], [x_3, x_3], [A_n, A_s])
-    return a.gcn_l4_1(l3[0], A_n, "sigmoid"), a.gcn_l4_2(l3[1], A_n, "sigmoid")
+    x_3_1, x_3_2 = _level_own_adj([a.gcn_l3_1, a.gcn_l3_2], [x_3, x_3], [A_n, A_s], cache=cache).unbind(0)
+    return a.gcn_l4_1(x_3_1, A_n, "sigmoid"), a.gcn_l4_2(x_3_2, A_n, "sigmoid")
 
 
-def critic_forward_grouped(critic, inputs):
+def critic_forward_grouped(critic, inputs, cache=None):
     """multimodes_critic.forward, level by level (see above)."""
     c = critic
     x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p, self_g, self_t, other_g1, other_t1, other_g2, other_t2 = inputs
@@ -210,13 +255,14 @@ def critic_forward_grouped(critic, inputs):
     H = c.l1[0].lin.out_features
     bias = torch.cat([c.l1[i].bias for i in (0, 1, 2, 4, 5, 6, 7, 8, 9)])
     l1 = torch.relu(torch.baddbmm(bias.expand(B, N, 9 * H), A_n.expand(B, N, N), h)).reshape(B, N, 9, H)
-    x_1_1, x_1_2, x_1_3 = l1[:, :, 0], l1[:, :, 1], l1[:, :, 2]
-    x_1_a = [l1[:, :, 3 + i] for i in range(6)]
+    parts = l1.unbind(2)                                   # (one stack in the backward pass instead of nine fill + copy + add)
+    x_1_1, x_1_2, x_1_3 = parts[:3]
+    x_1_a = list(parts[3:])
     x_1_4 = _tile_pool(c.l1[3](x_p, A_p, "relu").sum(dim=1), N)
     # level 2: eleven layers, each with its own input; adjacencies A_n, A_n_ts, A_n_cs, A_s, A_n x 6, A_n
     xs = [x_1_1, x_1_2, x_1_2, x_1_3] + x_1_a + [x_1_4]
     adjs = [A_n, A_n_ts, A_n_cs, A_s] + [A_n] * 7
-    l2 = _level_own_adj(list(c.l2), xs, adjs)                                                         # [11,B,N,H]
+    l2 = _level_own_adj(list(c.l2), xs, adjs, cache=cache)                                            # [11,B,N,H]
     # 11 x GlobalSumPool -> Concatenate: [B, 11*H]
     q = l2.sum(dim=2).permute(1, 0, 2).reshape(B, 11 * H)
     q = torch.relu(c.dense_1(q))
@@ -482,9 +528,10 @@ class MADDPG:
             # 3 x batch samples: 6 network passes instead of 18 (the update is bound by its kernel count)
             nb = NS[0][0].shape[0]
             NSc = [torch.cat([NS[f][k] for f in range(3)], dim=0) for k in range(len(NS[0]))]
-            na = par([lambda ag=ag: actor_forward_grouped(ag.target_actor_model, self._actor_in(NSc)) for ag in self.agents])
+            cn, cs = _level_adjacencies(NSc), _level_adjacencies(S)      # data only: shared by every pass over that minibatch
+            na = par([lambda ag=ag: actor_forward_grouped(ag.target_actor_model, self._actor_in(NSc), cn) for ag in self.agents])
             tq = par([lambda ag=ag, o=orders[i]: critic_forward_grouped(
-                ag.target_critic_model, NSc + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1], na[o[2]][0], na[o[2]][1]])
+                ag.target_critic_model, NSc + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1], na[o[2]][0], na[o[2]][1]], cn)
                 for i, ag in enumerate(self.agents)])
             q_next = [[tq[i][f * nb:(f + 1) * nb] for i in range(3)] for f in range(3)]
         # The three critic updates depend on nothing another network's update changes (replayed actions, target networks): they
@@ -496,7 +543,7 @@ class MADDPG:
             # TD target; `done` never fires in the reference (it compares an action array with `is 1`)
             y = R[:, i:i + 1] + self.gamma * (q_next[0][i] + q_next[1][i] + q_next[2][i]) / 3
             ag.critic_opt.zero_grad(set_to_none=True)
-            loss = torch.mean((critic_forward_grouped(ag.critic_model, S + flat(o)) - y) ** 2)
+            loss = torch.mean((critic_forward_grouped(ag.critic_model, S + flat(o), cs) - y) ** 2)
             loss.backward()      # (autograd.grad + `p.grad = g` would save backward()'s clone per parameter, but the gradients are then
             #                       slices of the levels' stacked gradients and PyTorch's multi-tensor Adam falls back to one launch
             #                       per tensor: 1 646 -> 1 991 launches when tried)
@@ -514,18 +561,18 @@ class MADDPG:
         # that is asked for -- autograd.grad is taken with respect to agent i's parameters only -- so they run without a graph.)
         def no_grad_eval(a2):
             with torch.no_grad():
-                return actor_forward_grouped(a2.actor_model, self._actor_in(S))
+                return actor_forward_grouped(a2.actor_model, self._actor_in(S), cs)
 
         frozen = {}          # no-gradient evaluations that are still valid: actor j's weights only change in iteration j
         for i, ag in enumerate(self.agents):
             o = orders[i]
             todo = [j for j in range(len(self.agents)) if j != i and j not in frozen]
-            res = par([(lambda: actor_forward_grouped(ag.actor_model, self._actor_in(S)))] + [lambda a2=self.agents[j]: no_grad_eval(a2) for j in todo])
+            res = par([(lambda: actor_forward_grouped(ag.actor_model, self._actor_in(S), cs))] + [lambda a2=self.agents[j]: no_grad_eval(a2) for j in todo])
             for j, r_ in zip(todo, res[1:]):
                 frozen[j] = r_
             preds = [res[0] if j == i else frozen[j] for j in range(len(self.agents))]
             q = critic_forward_grouped(ag.critic_model, S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
-                                                             preds[o[2]][1]])
+                                                             preds[o[2]][1]], cs)
             actor_loss = -q.mean()
             ap = list(ag.actor_model.parameters())
             for p in ap:

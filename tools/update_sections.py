@@ -1,0 +1,72 @@
+"""Diagnostic: device kernels per section of the MADDPG update (grouped passes, backward, clip, optimiser steps), torch.profiler."""
+import os, sys, contextlib, io
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "mop-truss-marl_amd"), ROOT]
+import torch
+from torch.profiler import profile, ProfilerActivity
+import truss_mi355 as tm
+from truss_mi355 import marl, synthetic
+import master_DDPG_truss2D_MO as M
+import truss2D_RL as RL
+
+topo = tm.TrussTopology.grid(8)
+B = 512
+rl = RL.MADDPG(M.lr, M.ep, M.epd, M.gamma, M.a_nn, M.c_nn, 100, M.num_agents, M.num_action, M.mu, M.theta, M.sigma, device="cuda")
+eng = marl.BatchedMARL(topo, B, rl, max_front=20, device="cuda", replay_capacity=8192, batch_size=32, tune_update_gemms=False)
+eng.use_train_graph = False
+b = synthetic.random_batch(topo, B, 3)
+eng.reset(b["x"], b["target"], b["y_max"], b["d_min"], b["max_def"], b["load_x"], b["load_y"], b["is_roof"], b["y"], b["sec"])
+with contextlib.redirect_stdout(io.StringIO()):
+    for _ in range(3):
+        eng.game_step_all(train=True)
+S, NS, ag, at, R = eng.replay.sample(32, eng.gen)
+A = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
+st = eng._net_state(S)
+acts = [A[0][0], A[0][1], A[1][0], A[1][1], A[2][0], A[2][1]]
+a0 = rl.agents[0]
+cs = RL._level_adjacencies(st)
+
+
+def count(tag, fn, detail=False):
+    fn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    kern = [(e.count, e.key) for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA]
+    print(f"{tag:44s} {sum(c for c, _ in kern):5d} kernels")
+    if detail:
+        for c, k in sorted(kern, reverse=True)[:14]:
+            print("      ", c, k[:100])
+
+
+def critic_fb():
+    for p in a0.critic_model.parameters():
+        p.grad = None
+    RL.critic_forward_grouped(a0.critic_model, st + acts, cs).pow(2).mean().backward()
+
+
+def actor_fb():
+    ap = list(a0.actor_model.parameters())
+    g, t = RL.actor_forward_grouped(a0.actor_model, rl._actor_in(st), cs)
+    q = RL.critic_forward_grouped(a0.critic_model, st + [g, t] + acts[2:], cs)
+    grads = torch.autograd.grad(-q.mean(), ap, allow_unused=True)
+    for p, g_ in zip(ap, grads):
+        p.grad = g_
+
+
+with torch.no_grad():
+    count("actor forward (no grad)", lambda: RL.actor_forward_grouped(a0.actor_model, rl._actor_in(st), cs), True)
+    count("critic forward (no grad)", lambda: RL.critic_forward_grouped(a0.critic_model, st + acts, cs), True)
+count("critic forward + backward", critic_fb, True)
+count("actor + critic forward, backward to the actor", actor_fb, True)
+cp = list(a0.critic_model.parameters())
+count("clip (critic)", lambda: RL._clip_each(cp))
+count("critic Adam step", lambda: a0.critic_opt.step())
+ap = list(a0.actor_model.parameters())
+count("clip (actor)", lambda: RL._clip_each(ap))
+count("actor fresh-Adam step", lambda: RL._fresh_adam_step(ap, 1e-4, 1e-7))
+count("level adjacencies", lambda: RL._level_adjacencies(st))
+A3 = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
+nst = [eng._net_state(ns) for ns in NS]
+count("whole update", lambda: rl.train_on_batch(st, nst, A3, R))
