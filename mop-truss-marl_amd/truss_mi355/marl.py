@@ -431,6 +431,15 @@ class BatchedMARL:
                             torch.cuda.tunable.tuning_enable(False)
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 torch.cuda.synchronize(self.device)
+                d_ = getattr(self.rl, "dist", None)
+                if d_ is not None and d_.is_initialized():
+                    # The process group's watchdog thread polls the events of every eagerly enqueued collective until it has seen
+                    # it complete (about every 100 ms).  A poll that lands inside the capture below, on an event of the stream the
+                    # captured collectives run on, aborts the process (hipErrorCapturedEvent; this PyTorch build does not hold a
+                    # capture back for pending polls).  The warm-up's collectives have completed (synchronize above): wait until
+                    # the watchdog has retired them.
+                    time.sleep(0.5)
+
                 def restore():      # weights, Adam moments and loss log back to the state before the warm-up
                     with torch.no_grad():
                         for n, sp in zip(nets, snap):
