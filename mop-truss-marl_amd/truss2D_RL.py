@@ -133,141 +133,208 @@ class multimodes_critic(nn.Module):
         return self.dense_out(q)
 
 
-# ---- level-wise ("grouped") evaluation of the networks for the MADDPG update -----------------------------------------------
-# At batch 32 a GCN layer is four small launches forward (X W, A H, + b, activation) and about seven backward, and a critic has 21 of
-# them although it is only two levels deep: the update is bound by its kernel count (2 312 launches, 9.5 ms as a replayed hipGraph).
-# The layers of one level do not depend on each other, so they are evaluated TOGETHER: the products X_i W_i of a level as one batched
-# GEMM over the stacked operands, the neighbourhood sums as one batched GEMM with bias (baddbmm) over the stacked adjacencies -- or,
-# where the layers share one adjacency, over the layers' outputs laid side by side along the channels -- and one activation.  Same
-# parameters (the modules' own tensors: state_dict, checkpoints and the per-layer `forward` are untouched), same mathematics; the
-# GEMMs sum in a different order (tests/test_master_rl.py::test_grouped_forward_matches_layerwise: outputs <= 1e-5, gradients <= 1e-4
-# of their scale).
+# ---- level-wise evaluation of the networks for the MADDPG update ------------------------------------------------------------------
+# At batch 32 a GCN layer is four small launches forward (X W, A H, + b, activation) and about seven backward, a critic has 21 of
+# them although it is only two levels deep, and an update passes through nineteen networks: it is bound by its kernel count (2 312
+# launches, 9.5 ms as a replayed hipGraph, when evaluated layer by layer).  The layers of one level do not depend on each other --
+# nor do the same levels of DIFFERENT networks (the three target actors, the three critics ...) -- so a level is evaluated as ONE
+# operation over all of them (`gcn_level`, an autograd Function with a hand-written backward):
+#   forward   X'_i = A_i X_i, out_i = act(X'_i W_i^T + b_i)      one fused launch for the whole level on the GPU (truss_gcn_level,
+#             csrc/truss_gcn.h: MFMA, every layer of the level a slice of the grid) -- or, per group of equally shaped layers, two
+#             batched GEMMs over stacked operands (CPU, and the reference for the kernel);
+#   backward  dZ = dOut * act'(out);  db = sum dZ;  dW = dZ^T X'  (one batched GEMM per group: X' was kept);
+#             dX = A^T (dZ W)  (two batched GEMMs, only where an input asks for it).
+# The networks are written as generators that yield one level's requests at a time (`_actor_steps`, `_critic_steps`);
+# `run_networks` steps several of them in lockstep and hands each level of all of them to `gcn_level` together.  Same parameters
+# (the modules' own tensors: state_dict, checkpoints and the per-layer `forward` are untouched), same mathematics in a different
+# summation order (tests/test_master_rl.py::test_grouped_forward_matches_layerwise: outputs <= 1e-5, gradients <= 1e-4 of their
+# scale).
 
-class _LevelMM(torch.autograd.Function):
-    """H[i] = X[i] @ W[i]^T for the stacked inputs X [n, M, K] and the stacked kernels W [n, C, K] (nn.Linear layout).  torch.bmm
-    with the transposed stack does the same forward; its backward hands the kernels' gradient back as a TRANSPOSED view, the
-    per-layer slices are then not contiguous, and every multi-tensor step that follows (clip, Adam, the flat all-reduce buffer)
-    falls back to one launch per parameter tensor.  Here the gradient is produced in the kernels' own layout."""
+_LEVEL_FORWARD = None      # optional accelerator: callable(groups, xs, ws, bs) -> ([out_g], [xagg_g]) or None (truss_mi355.marl sets it)
+
+
+def set_level_forward(fn):
+    """Install (or, with None, remove) the fused level-forward; see `_GcnLevel.forward` for its contract."""
+    global _LEVEL_FORWARD
+    _LEVEL_FORWARD = fn
+
+
+class _Group:
+    """equally shaped layers of a level: requests `idx`, activation, stacked adjacencies [n B, N, N]"""
+    __slots__ = ("idx", "act", "a", "adjs", "shape")
+
+    def __init__(self, idx, act, a, adjs, shape):
+        self.idx, self.act, self.a, self.adjs, self.shape = idx, act, a, adjs, shape
+
+
+def _adj_stack(adjs, B, N, cache=None):
+    """the adjacencies of a group, stacked for the batched GEMMs: [n * B, N, N] (data only: cached for the minibatch)"""
+    key = (B,) + tuple(id(a_) for a_ in adjs)
+    hit = None if cache is None else cache.get(key)
+    if hit is not None:
+        return hit[0]
+    a = torch.stack([a_.expand(B, N, N) for a_ in adjs]).reshape(len(adjs) * B, N, N)
+    if cache is not None:
+        cache[key] = (a, tuple(adjs))                          # (the tensors are kept: their ids stay unique while the cache lives)
+    return a
+
+
+class _GcnLevel(torch.autograd.Function):
+    """apply(groups, *xs, *ws, *bs) -> one tensor [n_g, B, N, C] per group (see the section comment)."""
 
     @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return torch.bmm(x, w.transpose(1, 2))
+    def forward(ctx, groups, *tensors):
+        L = len(tensors) // 3
+        xs, ws, bs = tensors[:L], tensors[L:2 * L], tensors[2 * L:]
+        want_grad = any(ctx.needs_input_grad[1:])
+        outs = xaggs = None
+        if _LEVEL_FORWARD is not None and xs[0].is_cuda:
+            fused = _LEVEL_FORWARD(groups, xs, ws, bs, want_grad)
+            if fused is not None:
+                outs, xaggs = fused
+        if outs is None:
+            outs, xaggs = [], []
+            for g in groups:
+                n, (B, N, K), C = len(g.idx), g.shape, ws[g.idx[0]].shape[0]
+                x0 = xs[g.idx[0]]
+                xst = x0.expand(n, B, N, K) if all(xs[i] is x0 for i in g.idx) else torch.stack([xs[i] for i in g.idx])
+                xa = torch.bmm(g.a, xst.reshape(n * B, N, K)).view(n, B * N, K)                    # X' = A X
+                wst = torch.stack([ws[i] for i in g.idx])                                          # [n, C, K]
+                bst = torch.stack([bs[i] for i in g.idx])[:, None, :]                              # [n, 1, C]
+                o = torch.baddbmm(bst, xa, wst.transpose(1, 2))
+                o = torch.relu_(o) if g.act == "relu" else torch.sigmoid_(o) if g.act == "sigmoid" else o
+                outs.append(o.view(n, B, N, C))
+                xaggs.append(xa)
+        ctx.groups, ctx.L = groups, L
+        if want_grad:
+            ctx.save_for_backward(*outs, *xaggs, *ws)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dh):
-        x, w = ctx.saved_tensors
-        dx = torch.bmm(dh, w) if ctx.needs_input_grad[0] else None
-        dw = torch.bmm(dh.transpose(1, 2), x) if ctx.needs_input_grad[1] else None       # [n, C, K], contiguous
-        return dx, dw
+    def backward(ctx, *douts):
+        groups, L = ctx.groups, ctx.L
+        G = len(groups)
+        saved = ctx.saved_tensors
+        outs, xaggs, ws = saved[:G], saved[G:2 * G], saved[2 * G:]
+        need = ctx.needs_input_grad
+        dx, dw, db = [None] * L, [None] * L, [None] * L
+        for gi, g in enumerate(groups):
+            if douts[gi] is None:
+                continue
+            n, (B, N, K) = len(g.idx), g.shape
+            o = outs[gi]
+            C = o.shape[-1]
+            d = douts[gi].contiguous()
+            dz = (torch.ops.aten.threshold_backward(d, o, 0.0) if g.act == "relu" else
+                  torch.ops.aten.sigmoid_backward(d, o) if g.act == "sigmoid" else d).view(n, B * N, C)
+            if any(need[1 + L + i] or need[1 + 2 * L + i] for i in g.idx):
+                for i, piece in zip(g.idx, torch.bmm(dz.transpose(1, 2), xaggs[gi]).unbind(0)):     # dW = dZ^T X'   [n, C, K]
+                    dw[i] = piece
+                for i, piece in zip(g.idx, dz.sum(dim=1).unbind(0)):
+                    db[i] = piece
+            if any(need[1 + i] for i in g.idx):
+                gw = torch.bmm(dz, torch.stack([ws[i] for i in g.idx]))                             # dZ W           [n, B N, K]
+                gx = torch.bmm(g.a.transpose(1, 2), gw.view(n * B, N, K)).view(n, B, N, K)         # A^T (dZ W)
+                for i, piece in zip(g.idx, gx.unbind(0)):
+                    dx[i] = piece                          # (one tensor passed for several layers: autograd adds per argument)
+        return (None, *dx, *dw, *db)
+
+
+def gcn_level(reqs, cache=None):
+    """reqs: [(GCNConv layer, x [B,N,K], adjacency [B,N,N] or [1,N,N], activation)] -> [act(adj @ x @ W^T + b)] in request order.
+    Layers of equal shapes and activation form a group (one set of batched GEMMs forward and backward)."""
+    by_key = {}
+    for i, (layer, x, adj, act) in enumerate(reqs):
+        by_key.setdefault((tuple(x.shape), layer.lin.out_features, act), []).append(i)
+    groups = []
+    for (shape, _, act), idx in by_key.items():
+        adjs = [reqs[i][2] for i in idx]
+        groups.append(_Group(idx, act, _adj_stack(adjs, shape[0], shape[1], cache), adjs, shape))
+    outs = _GcnLevel.apply(groups, *[r[1] for r in reqs], *[r[0].lin.weight for r in reqs], *[r[0].bias for r in reqs])
+    res = [None] * len(reqs)
+    for g, o in zip(groups, outs):
+        # unbind, not o[i]: its backward is ONE stack of the pieces' gradients; every select's backward is a fill, a copy and an add
+        for i, piece in zip(g.idx, o.unbind(0)):
+            res[i] = piece
+    return res
 
 
 def _ready(layers):
     return not any(isinstance(L.lin.weight, nn.parameter.UninitializedParameter) for L in layers)
 
 
-def _level_shared_adj(layers, xs, adj, act="relu"):
-    """layers[i](xs[i], adj) for all i, one adjacency [B,N,N]: outputs side by side, [B, N, n, C]."""
-    n, C = len(layers), layers[0].lin.out_features
-    if all(x is xs[0] for x in xs):                       # one input too: a single wide GEMM
-        h = nn.functional.linear(xs[0], torch.cat([L.lin.weight for L in layers], dim=0))            # [B,N,n*C]
-    elif len({x.shape[-1] for x in xs}) == 1:
-        B, N, K = xs[0].shape
-        h = _LevelMM.apply(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]))
-        h = h.reshape(n, B, N, C).permute(1, 2, 0, 3).reshape(B, N, n * C)
-    else:
-        h = torch.cat([nn.functional.linear(x, L.lin.weight) for L, x in zip(layers, xs)], dim=-1)
-    B, N = h.shape[0], h.shape[1]
-    bias = torch.cat([L.bias for L in layers])
-    out = torch.baddbmm(bias.expand(B, N, n * C), adj.expand(B, N, N), h)
-    out = torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
-    return out.reshape(B, N, n, C)
+def _actor_steps(a, inputs):
+    """multimodes_actor.forward as a generator: yields the requests of one level, receives that level's outputs"""
+    x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p = inputs
+    o = yield [(a.gcn_l1_1, x_n, A_n, "relu"), (a.gcn_l1_2, x_n, A_n, "relu"), (a.gcn_l1_3, x_n, A_n, "relu"),
+               (a.gcn_l1_4, x_p, A_p, "relu")]
+    x_1_4 = _tile_pool(o[3].sum(dim=1), x_n.shape[1])                                                # GlobalSumPool, tiled
+    o = yield [(a.gcn_l2_1, o[0], A_n, "relu"), (a.gcn_l2_2, o[1], A_n_ts, "relu"), (a.gcn_l2_3, o[1], A_n_cs, "relu"),
+               (a.gcn_l2_4, o[2], A_s, "relu"), (a.gcn_l2_5, x_1_4, A_n, "relu")]
+    x_3 = torch.stack(o).sum(dim=0)
+    o = yield [(a.gcn_l3_1, x_3, A_n, "relu"), (a.gcn_l3_2, x_3, A_s, "relu")]
+    o = yield [(a.gcn_l4_1, o[0], A_n, "sigmoid"), (a.gcn_l4_2, o[1], A_n, "sigmoid")]
+    return o[0], o[1]
 
 
-def _adj_stack(adjs, B, N, cache=None):
-    """the adjacencies of a level, stacked for the batched GEMM: [n * B, N, N]"""
-    key = (B,) + tuple(id(a_) for a_ in adjs)
-    a = None if cache is None else cache.get(key)
-    if a is None:
-        a = torch.stack([a_.expand(B, N, N) for a_ in adjs]).reshape(len(adjs) * B, N, N)
-        if cache is not None:
-            cache[key] = a
-            cache.setdefault("_keep", []).extend(adjs)        # the ids in the key stay unique while the cache lives
-    return a
+def _critic_steps(c, inputs):
+    """multimodes_critic.forward as a generator (see _actor_steps)"""
+    x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p, self_g, self_t, other_g1, other_t1, other_g2, other_t2 = inputs
+    acts = [self_g, self_t, other_g1, other_t1, other_g2, other_t2]
+    o = yield ([(c.l1[i], x_n, A_n, "relu") for i in range(3)] + [(c.l1[3], x_p, A_p, "relu")] +
+               [(c.l1[4 + i], a_, A_n, "relu") for i, a_ in enumerate(acts)])
+    x_1_4 = _tile_pool(o[3].sum(dim=1), x_n.shape[1])
+    xs = [o[0], o[1], o[1], o[2]] + list(o[4:10]) + [x_1_4]
+    adjs = [A_n, A_n_ts, A_n_cs, A_s] + [A_n] * 7
+    o = yield [(c.l2[i], xs[i], adjs[i], "relu") for i in range(11)]
+    # 11 x GlobalSumPool -> Concatenate, as one reduction: [B, 11, N, C] summed over the nodes = the 11 pooled vectors side by side
+    q = torch.stack(o, dim=1).sum(dim=2).flatten(1)
+    q = torch.relu(c.dense_1(q))
+    q = torch.relu(c.dense_2(q))
+    return c.dense_out(q)
 
 
-def _level_adjacencies(S):
-    """The three adjacency stacks the grouped passes over minibatch S = [x_n, A_n, A_s, A_n_ts, A_n_cs, ...] need (actor levels 2 and
-    3, critic level 2), built once, on the CALLER's stream: the passes of one update run on parallel streams and only read them."""
-    x_n, A_n, A_s, A_n_ts, A_n_cs = S[:5]
-    B, N = x_n.shape[0], x_n.shape[1]
-    cache = {}
-    for adjs in ([A_n, A_n_ts, A_n_cs, A_s, A_n], [A_n, A_s], [A_n, A_n_ts, A_n_cs, A_s] + [A_n] * 7):
-        _adj_stack(adjs, B, N, cache)
-    return cache
+def run_networks(gens, cache=None):
+    """Step the network generators in lockstep: level k of all of them is ONE `gcn_level`.  Returns their return values."""
+    reqs = [next(g) for g in gens]
+    results = [None] * len(gens)
+    live = list(range(len(gens)))
+    while live:
+        outs = gcn_level([r for k in live for r in reqs[k]], cache)
+        pos, still = 0, []
+        for k in live:
+            o = outs[pos:pos + len(reqs[k])]
+            pos += len(reqs[k])
+            try:
+                reqs[k] = gens[k].send(o)
+                still.append(k)
+            except StopIteration as done:
+                results[k] = done.value
+        live = still
+    return results
 
 
-def _level_own_adj(layers, xs, adjs, act="relu", cache=None):
-    """layers[i](xs[i], adjs[i]) for all i (same shapes): [n, B, N, C].  `cache`: a dict that lives for one update -- the stacked
-    adjacencies are data only, the same for every network evaluated on the same minibatch."""
-    n, C = len(layers), layers[0].lin.out_features
-    B, N, K = xs[0].shape
-    h = _LevelMM.apply(torch.stack(xs).reshape(n, B * N, K), torch.stack([L.lin.weight for L in layers]))              # [n, B*N, C]
-    a = _adj_stack(adjs, B, N, cache)
-    bias = torch.stack([L.bias for L in layers])[:, None, None, :].expand(n, B, N, C).reshape(n * B, N, C)
-    out = torch.baddbmm(bias, a, h.reshape(n * B, N, C))
-    out = torch.relu(out) if act == "relu" else torch.sigmoid(out) if act == "sigmoid" else out
-    return out.reshape(n, B, N, C)
+def _actor_layers(a):
+    return [a.gcn_l1_1, a.gcn_l1_2, a.gcn_l1_3, a.gcn_l1_4, a.gcn_l2_1, a.gcn_l2_2, a.gcn_l2_3, a.gcn_l2_4, a.gcn_l2_5, a.gcn_l3_1,
+            a.gcn_l3_2, a.gcn_l4_1, a.gcn_l4_2]
+
+
+def _critic_is_ready(c):
+    return _ready(list(c.l1) + list(c.l2)) and not isinstance(c.dense_1.weight, nn.parameter.UninitializedParameter)
 
 
 def actor_forward_grouped(actor, inputs, cache=None):
     """multimodes_actor.forward, level by level (see above)."""
-    a = actor
-    x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p = inputs
-    layers = [a.gcn_l1_1, a.gcn_l1_2, a.gcn_l1_3, a.gcn_l1_4, a.gcn_l2_1, a.gcn_l2_2, a.gcn_l2_3, a.gcn_l2_4, a.gcn_l2_5, a.gcn_l3_1,
-              a.gcn_l3_2, a.gcn_l4_1, a.gcn_l4_2]
-    if not _ready(layers):
-        return a(inputs)                                   # first call: let the lazy kernels materialise (Glorot) layer by layer
-    l1 = _level_shared_adj([a.gcn_l1_1, a.gcn_l1_2, a.gcn_l1_3], [x_n, x_n, x_n], A_n)              # [B,N,3,H]
-    # unbind, not l1[:, :, i]: its backward is ONE stack of the pieces' gradients; every select's backward is a fill, a copy and an
-    # add into the running sum
-    x_1_1, x_1_2, x_1_3 = l1.unbind(2)
-    x_1_4 = _tile_pool(a.gcn_l1_4(x_p, A_p, "relu").sum(dim=1), x_n.shape[1])
-    l2 = _level_own_adj([a.gcn_l2_1, a.gcn_l2_2, a.gcn_l2_3, a.gcn_l2_4, a.gcn_l2_5], [x_1_1, x_1_2, x_1_2, x_1_3, x_1_4],
-                        [A_n, A_n_ts, A_n_cs, A_s, A_n], cache=cache)
-    x_3 = l2.sum(dim=0)
-    x_3_1, x_3_2 = _level_own_adj([a.gcn_l3_1, a.gcn_l3_2], [x_3, x_3], [A_n, A_s], cache=cache).unbind(0)
-    return a.gcn_l4_1(x_3_1, A_n, "sigmoid"), a.gcn_l4_2(x_3_2, A_n, "sigmoid")
+    if not _ready(_actor_layers(actor)):
+        return actor(inputs)                               # first call: let the lazy kernels materialise (Glorot) layer by layer
+    return run_networks([_actor_steps(actor, inputs)], cache)[0]
 
 
 def critic_forward_grouped(critic, inputs, cache=None):
     """multimodes_critic.forward, level by level (see above)."""
-    c = critic
-    x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p, self_g, self_t, other_g1, other_t1, other_g2, other_t2 = inputs
-    if not _ready(list(c.l1) + list(c.l2)) or isinstance(c.dense_1.weight, nn.parameter.UninitializedParameter):
-        return c(inputs)
-    acts = [self_g, self_t, other_g1, other_t1, other_g2, other_t2]
-    # level 1 over the node graph: the three layers on x_n and the six on the actions share A_n -> nine outputs side by side
-    h_n = nn.functional.linear(x_n, torch.cat([c.l1[0].lin.weight, c.l1[1].lin.weight, c.l1[2].lin.weight], dim=0))
-    h_a = [nn.functional.linear(a_, c.l1[4 + i].lin.weight) for i, a_ in enumerate(acts)]
-    h = torch.cat([h_n] + h_a, dim=-1)                                                               # [B,N,9*H]
-    B, N = h.shape[0], h.shape[1]
-    H = c.l1[0].lin.out_features
-    bias = torch.cat([c.l1[i].bias for i in (0, 1, 2, 4, 5, 6, 7, 8, 9)])
-    l1 = torch.relu(torch.baddbmm(bias.expand(B, N, 9 * H), A_n.expand(B, N, N), h)).reshape(B, N, 9, H)
-    parts = l1.unbind(2)                                   # (one stack in the backward pass instead of nine fill + copy + add)
-    x_1_1, x_1_2, x_1_3 = parts[:3]
-    x_1_a = list(parts[3:])
-    x_1_4 = _tile_pool(c.l1[3](x_p, A_p, "relu").sum(dim=1), N)
-    # level 2: eleven layers, each with its own input; adjacencies A_n, A_n_ts, A_n_cs, A_s, A_n x 6, A_n
-    xs = [x_1_1, x_1_2, x_1_2, x_1_3] + x_1_a + [x_1_4]
-    adjs = [A_n, A_n_ts, A_n_cs, A_s] + [A_n] * 7
-    l2 = _level_own_adj(list(c.l2), xs, adjs, cache=cache)                                            # [11,B,N,H]
-    # 11 x GlobalSumPool -> Concatenate: [B, 11*H]
-    q = l2.sum(dim=2).permute(1, 0, 2).reshape(B, 11 * H)
-    q = torch.relu(c.dense_1(q))
-    q = torch.relu(c.dense_2(q))
-    return c.dense_out(q)
+    if not _critic_is_ready(critic):
+        return critic(inputs)
+    return run_networks([_critic_steps(critic, inputs)], cache)[0]
 
 
 _seg_cache: dict = {}
@@ -308,6 +375,7 @@ class SharedStepAdam:
         self.params = list(params)
         self.lr, self.eps, (self.b1, self.b2) = float(lr), float(eps), betas
         self.step_t, self.exp_avg, self.exp_avg_sq = None, None, None
+        self.n_steps = 0                 # host-side count of step calls (capture counts once): only compared between optimisers
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -317,28 +385,40 @@ class SharedStepAdam:
         """the optimiser's state as a flat list (empty before the first step): step counter, first moments, second moments"""
         return [] if self.step_t is None else [self.step_t] + self.exp_avg + self.exp_avg_sq
 
-    @torch.no_grad()
     def step(self):
-        ps = self.params
-        if self.step_t is None:
-            self.step_t = torch.zeros((), dtype=torch.float64, device=ps[0].device)   # float64: 1 - 0.999^t cancels badly in float32
-            self.exp_avg = [torch.zeros_like(p) for p in ps]
-            self.exp_avg_sq = [torch.zeros_like(p) for p in ps]
+        SharedStepAdam.step_together([self])
+
+    @staticmethod
+    @torch.no_grad()
+    def step_together(opts):
+        """`step()` of every optimiser in `opts` as ONE set of multi-tensor launches.  The optimisers must have the same
+        hyper-parameters and must always have stepped together (the three critics of a MADDPG): their step counters then hold the
+        same number and the first one's bias corrections serve all."""
+        o0 = opts[0]
+        if any((o.lr, o.eps, o.b1, o.b2, o.n_steps) != (o0.lr, o0.eps, o0.b1, o0.b2, o0.n_steps) for o in opts):
+            raise RuntimeError("SharedStepAdam.step_together: optimisers differ in hyper-parameters or step count")
+        for o in opts:
+            if o.step_t is None:
+                o.step_t = torch.zeros((), dtype=torch.float64, device=o.params[0].device)   # float64: 1 - 0.999^t cancels badly in float32
+                o.exp_avg = [torch.zeros_like(p) for p in o.params]
+                o.exp_avg_sq = [torch.zeros_like(p) for p in o.params]
+            o.n_steps += 1
+        ps = [p for o in opts for p in o.params]
         grads = [p.grad for p in ps]
         if any(g is None for g in grads):
             raise RuntimeError("SharedStepAdam: every parameter must have a gradient (the list steps together)")
-        m, v = self.exp_avg, self.exp_avg_sq
-        self.step_t += 1
-        bc1 = 1 - torch.pow(self.b1, self.step_t)
-        bc2_sqrt = (1 - torch.pow(self.b2, self.step_t)).sqrt_().float()
-        torch._foreach_lerp_(m, grads, 1 - self.b1)
-        torch._foreach_mul_(v, self.b2)
-        torch._foreach_addcmul_(v, grads, grads, value=1 - self.b2)
+        m, v = [t for o in opts for t in o.exp_avg], [t for o in opts for t in o.exp_avg_sq]
+        torch._foreach_add_([o.step_t for o in opts], 1)
+        bc1 = 1 - torch.pow(o0.b1, o0.step_t)
+        bc2_sqrt = (1 - torch.pow(o0.b2, o0.step_t)).sqrt_().float()
+        torch._foreach_lerp_(m, grads, 1 - o0.b1)
+        torch._foreach_mul_(v, o0.b2)
+        torch._foreach_addcmul_(v, grads, grads, value=1 - o0.b2)
         den = torch._foreach_sqrt(v)
         torch._foreach_div_(den, bc2_sqrt)
-        torch._foreach_add_(den, self.eps)
+        torch._foreach_add_(den, o0.eps)
         upd = torch._foreach_div(m, den)
-        torch._foreach_mul_(upd, (-self.lr / bc1).float())
+        torch._foreach_mul_(upd, (-o0.lr / bc1).float())
         torch._foreach_add_(ps, upd)
 
 
@@ -518,61 +598,63 @@ class MADDPG:
         flat = lambda order: [A[order[0]][0], A[order[0]][1], A[order[1]][0], A[order[1]][1], A[order[2]][0], A[order[2]][1]]
         orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]          # (self, other1, other2) per agent (:561-563)
         self._ensure_ready(S, flat(orders[0]))
-        # Independent network passes run side by side: inside a hipGraph capture (truss_mi355/marl.py) each goes to its own stream,
-        # forked from and joined back to the capturing stream, so that the replayed graph has parallel branches -- at batch 32 a
-        # network pass is a chain of ~100 kernels that each fill a few percent of the chip.  Eager runs (warm-up, CPU tests, the
-        # per-env reference loop) keep one stream: the same operations in the same order per network, hence the same numbers.
+        # Passes that do not depend on each other go through `run_networks` TOGETHER (one operation per level for all of them); what
+        # must stay apart (a pass with and one without gradients) runs side by side: inside a hipGraph capture (truss_mi355/marl.py)
+        # each such branch goes to its own stream, forked from and joined back to the capturing stream, so that the replayed graph
+        # has parallel branches.  Eager runs (warm-up, CPU tests, the per-env reference loop) keep one stream: same operations.
         par = self._branches()
+        agents = self.agents
+        pair = lambda preds, o: [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0], preds[o[2]][1]]
+        cn, cs = {}, {}                  # per-minibatch caches of the stacked adjacencies (data only)
         with torch.no_grad():
-            # the three next states (one per agent's move, :561-600) go through the target networks as ONE batch of
-            # 3 x batch samples: 6 network passes instead of 18 (the update is bound by its kernel count)
+            # the three next states (one per agent's move, :561-600) go through the target networks as ONE batch of 3 x batch
+            # samples, and the three target actors -- then the three target critics -- level by level together
             nb = NS[0][0].shape[0]
             NSc = [torch.cat([NS[f][k] for f in range(3)], dim=0) for k in range(len(NS[0]))]
-            cn, cs = _level_adjacencies(NSc), _level_adjacencies(S)      # data only: shared by every pass over that minibatch
-            na = par([lambda ag=ag: actor_forward_grouped(ag.target_actor_model, self._actor_in(NSc), cn) for ag in self.agents])
-            tq = par([lambda ag=ag, o=orders[i]: critic_forward_grouped(
-                ag.target_critic_model, NSc + [na[o[0]][0], na[o[0]][1], na[o[1]][0], na[o[1]][1], na[o[2]][0], na[o[2]][1]], cn)
-                for i, ag in enumerate(self.agents)])
-            q_next = [[tq[i][f * nb:(f + 1) * nb] for i in range(3)] for f in range(3)]
+            na = run_networks([_actor_steps(ag.target_actor_model, self._actor_in(NSc)) for ag in agents], cn)
+            tq = run_networks([_critic_steps(ag.target_critic_model, NSc + pair(na, orders[i])) for i, ag in enumerate(agents)], cn)
+            # TD targets; `done` never fires in the reference (it compares an action array with `is 1`)
+            tq3 = torch.stack(tq, dim=1).view(3, nb, 3)                                   # [next state f, sample, agent]
+            y = R + self.gamma * tq3.sum(dim=0) / 3                                        # [sample, agent]
         # The three critic updates depend on nothing another network's update changes (replayed actions, target networks): they
         # come first -- exactly the reference's results, since critic i is not touched between its own step and agent i's actor
-        # update (:603-629) -- and, data-parallel, their gradients travel as ONE flat buffer (one RCCL all-reduce for the three).
-
-        def critic_grads(i, ag):
-            o = orders[i]
-            # TD target; `done` never fires in the reference (it compares an action array with `is 1`)
-            y = R[:, i:i + 1] + self.gamma * (q_next[0][i] + q_next[1][i] + q_next[2][i]) / 3
-            ag.critic_opt.zero_grad(set_to_none=True)
-            loss = torch.mean((critic_forward_grouped(ag.critic_model, S + flat(o), cs) - y) ** 2)
-            loss.backward()      # (autograd.grad + `p.grad = g` would save backward()'s clone per parameter, but the gradients are then
-            #                       slices of the levels' stacked gradients and PyTorch's multi-tensor Adam falls back to one launch
-            #                       per tensor: 1 646 -> 1 991 launches when tried)
-            return loss.detach()                     # stays on the device: no synchronisation inside the update
-
-        for ag, loss in zip(self.agents, par([lambda i=i, ag=ag: critic_grads(i, ag) for i, ag in enumerate(self.agents)])):
-            ag.c_loss.append(loss)
-        cps = [list(ag.critic_model.parameters()) for ag in self.agents]
+        # update (:603-629) -- together, level by level; data-parallel, their gradients travel as ONE flat buffer (one RCCL
+        # all-reduce for the three).
+        qs = run_networks([_critic_steps(ag.critic_model, S + flat(orders[i])) for i, ag in enumerate(agents)], cs)
+        losses = ((torch.cat(qs, dim=1) - y) ** 2).mean(dim=0)                            # [agent]
+        cps = [list(ag.critic_model.parameters()) for ag in agents]
+        # autograd.grad, not backward(): the kernels' gradients are slices of their level's stacked gradient, and backward() would
+        # clone every one of them into .grad
+        grads = torch.autograd.grad(losses.sum(), [p for cp in cps for p in cp])
+        k = 0
+        for cp in cps:
+            for p in cp:
+                p.grad = grads[k]
+                k += 1
+        for i, ag in enumerate(agents):
+            ag.c_loss.append(losses[i].detach())     # stays on the device: no synchronisation inside the update
         _allreduce_grads(cps, self.dist)
-        for ag, cp in zip(self.agents, cps):
-            _clip_each(cp)
-            ag.critic_opt.step()
+        _clip_each([p for cp in cps for p in cp])
+        SharedStepAdam.step_together([ag.critic_opt for ag in agents])
         # The actor updates stay one after the other: agent i's loss re-evaluates ALL three actors (:617-629), i.e. it sees the
         # weights agents < i have just stepped to -- one collective per actor.  (The other two actors' passes carry no gradient
         # that is asked for -- autograd.grad is taken with respect to agent i's parameters only -- so they run without a graph.)
-        def no_grad_eval(a2):
+        def no_grad_eval(js, cache):
             with torch.no_grad():
-                return actor_forward_grouped(a2.actor_model, self._actor_in(S), cs)
+                return run_networks([_actor_steps(agents[j].actor_model, self._actor_in(S)) for j in js], cache)
 
         frozen = {}          # no-gradient evaluations that are still valid: actor j's weights only change in iteration j
-        for i, ag in enumerate(self.agents):
+        for i, ag in enumerate(agents):
             o = orders[i]
-            todo = [j for j in range(len(self.agents)) if j != i and j not in frozen]
-            res = par([(lambda: actor_forward_grouped(ag.actor_model, self._actor_in(S), cs))] + [lambda a2=self.agents[j]: no_grad_eval(a2) for j in todo])
-            for j, r_ in zip(todo, res[1:]):
-                frozen[j] = r_
-            preds = [res[0] if j == i else frozen[j] for j in range(len(self.agents))]
-            q = critic_forward_grouped(ag.critic_model, S + [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0],
-                                                             preds[o[2]][1]], cs)
+            todo = [j for j in range(len(agents)) if j != i and j not in frozen]
+            fns = [lambda c: run_networks([_actor_steps(ag.actor_model, self._actor_in(S))], c)[0]]
+            if todo:
+                fns.append(lambda c: no_grad_eval(todo, c))
+            res = par(fns, cs)
+            if todo:
+                frozen.update(zip(todo, res[1]))
+            preds = [res[0] if j == i else frozen[j] for j in range(len(agents))]
+            q = run_networks([_critic_steps(ag.critic_model, S + pair(preds, o))], cs)[0]
             actor_loss = -q.mean()
             ap = list(ag.actor_model.parameters())
             for p in ap:
@@ -588,23 +670,30 @@ class MADDPG:
             frozen = {j: v for j, v in frozen.items() if j != i}
 
     def _branches(self):
-        """callable(list of thunks) -> list of results; on side streams when the current CUDA stream is being captured"""
+        """callable(list of thunks(cache), cache) -> list of results; on side streams when the current CUDA stream is being captured.
+        Every branch gets its own view of the cache (reads fall through to the caller's, writes stay with the branch until the
+        join): an entry another branch computes on ITS stream is never read by a sibling."""
+        import collections
         dev = self.device
-        if dev.type != "cuda" or not torch.cuda.is_current_stream_capturing():
-            return lambda fns: [f() for f in fns]
-        if getattr(self, "_side_streams", None) is None:
+        capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing and getattr(self, "_side_streams", None) is None:
             self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
-        streams = self._side_streams
 
-        def run(fns):
-            cur = torch.cuda.current_stream(dev)
-            outs = []
-            for st, f in zip(streams, fns):
-                st.wait_stream(cur)                  # fork: the branch sees everything enqueued so far
-                with torch.cuda.stream(st):
-                    outs.append(f())
-            for st in streams[:len(fns)]:
-                cur.wait_stream(st)                  # join
+        def run(fns, cache):
+            views = [collections.ChainMap({}, cache) for _ in fns]
+            if not capturing or len(fns) == 1:
+                outs = [f(v) for f, v in zip(fns, views)]
+            else:
+                cur = torch.cuda.current_stream(dev)
+                outs = []
+                for st, f, v in zip(self._side_streams, fns, views):
+                    st.wait_stream(cur)                  # fork: the branch sees everything enqueued so far
+                    with torch.cuda.stream(st):
+                        outs.append(f(v))
+                for st in self._side_streams[:len(fns)]:
+                    cur.wait_stream(st)                  # join
+            for v in views:
+                cache.update(v.maps[0])
             return outs
         return run
 

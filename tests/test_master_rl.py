@@ -279,3 +279,98 @@ def test_grouped_forward_matches_layerwise():
         g2 = torch.autograd.grad(loss(fwd_g()), ps)
         for a, b in zip(g1, g2):
             assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
+
+
+def _update_batch(seed, B=5, N=12, P=20, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g) * scale
+    A = lambda n: torch.softmax(torch.randn(B, n, n, generator=g), -1)
+    state = lambda: [r(B, N, 13), A(N), A(N), A(N), A(N), torch.ones(B, N, N), r(B, P, 4), A(P)]
+    return state(), [state() for _ in range(3)], [(r(B, N, 2), r(B, N, 3)) for _ in range(3)], r(B, 3)
+
+
+def test_merged_network_passes_match_single_passes():
+    """`run_networks` over several networks at once (one `gcn_level` per level for all of them, the hand-written backward over the
+    stacked groups) against each network's own layer-by-layer forward: outputs, parameter gradients, and the gradient that flows
+    back into the critics' action inputs (the actor update's path)."""
+    import truss2D_RL as RL
+    torch.manual_seed(11)
+    S, _, A, _ = _update_batch(1, B=4)
+    ain = [S[0], S[1], S[2], S[3], S[4], S[6], S[7]]
+    actors = [RL.multimodes_actor(24, 2, 3) for _ in range(3)]
+    critics = [RL.multimodes_critic(24, 16) for _ in range(3)]
+    acts = [t.clone().requires_grad_() for a in A for t in a]
+    for a, c in zip(actors, critics):
+        a(ain), c(S + acts)                                   # materialise the lazy kernels
+    outs = RL.run_networks([RL._actor_steps(a, ain) for a in actors], {})
+    qs = RL.run_networks([RL._critic_steps(c, S + acts) for c in critics], {})
+    loss_m = sum((k + 1.0) * (o[0].sum() + o[1].pow(2).sum()) for k, o in enumerate(outs)) + sum((k + 2.0) * q.pow(2).mean() for k, q in enumerate(qs))
+    loss_s = sum((k + 1.0) * (o[0].sum() + o[1].pow(2).sum()) for k, o in enumerate(a(ain) for a in actors)) + \
+        sum((k + 2.0) * c(S + acts).pow(2).mean() for k, c in enumerate(critics))
+    for o, a in zip(outs, actors):
+        for x, y in zip(o, a(ain)):
+            torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
+    for q, c in zip(qs, critics):
+        torch.testing.assert_close(q, c(S + acts), rtol=1e-5, atol=1e-6)
+    wrt = [p for n in actors + critics for p in n.parameters()] + acts
+    for a, b in zip(torch.autograd.grad(loss_s, wrt), torch.autograd.grad(loss_m, wrt)):
+        assert a.shape == b.shape and b.is_contiguous()
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
+
+
+def _reference_order_update(rl, S, NS, A, R, critic_opts):
+    """One MADDPG update exactly as the reference orders it (train/code/truss2D_RL.py:561-689): agent after agent -- TD target from
+    the target networks, critic step (Adam, clipnorm 1 per tensor), then the actor step through the just-updated critic with a
+    fresh Adam -- every network evaluated by its own layer-by-layer forward, torch.optim.Adam for the arithmetic."""
+    import truss2D_RL as RL
+    ain = lambda s: [s[0], s[1], s[2], s[3], s[4], s[6], s[7]]
+    orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]
+    pick = lambda acts, o: [acts[o[0]][0], acts[o[0]][1], acts[o[1]][0], acts[o[1]][1], acts[o[2]][0], acts[o[2]][1]]
+
+    def clip(params):
+        for p in params:
+            if p.grad is not None:
+                p.grad.mul_(torch.clamp(1.0 / (p.grad.norm() + 1e-12), max=1.0))
+
+    with torch.no_grad():
+        q_next = []
+        for ns in NS:
+            na = [ag.target_actor_model(ain(ns)) for ag in rl.agents]
+            q_next.append([ag.target_critic_model(ns + pick(na, orders[i])) for i, ag in enumerate(rl.agents)])
+    for i, ag in enumerate(rl.agents):
+        y = R[:, i:i + 1] + rl.gamma * (q_next[0][i] + q_next[1][i] + q_next[2][i]) / 3
+        critic_opts[i].zero_grad()
+        torch.mean((ag.critic_model(S + pick(A, orders[i])) - y) ** 2).backward()
+        clip(ag.critic_model.parameters())
+        critic_opts[i].step()
+        preds = [a2.actor_model(ain(S)) for a2 in rl.agents]
+        loss = -ag.critic_model(S + pick(preds, orders[i])).mean()
+        ap = list(ag.actor_model.parameters())
+        for p, g in zip(ap, torch.autograd.grad(loss, ap)):
+            p.grad = g
+        clip(ap)
+        torch.optim.Adam(ap, lr=ag.lr * 0.1, eps=1e-7).step()
+
+
+def test_update_matches_the_reference_order_layer_by_layer():
+    """`MADDPG.train_on_batch` (critics first and together, merged level-wise passes, multi-tensor clip / Adam) against the
+    reference's own order of operations evaluated layer by layer: same weights after three updates on three minibatches."""
+    import copy
+    import master_DDPG_truss2D_MO as M
+    torch.manual_seed(5)
+    rl = _tiny_maddpg(M)
+    batches = [_update_batch(20 + k, scale=1.0 + k) for k in range(3)]
+    S, NS, A, R = batches[0]
+    rl._ensure_ready(S, [t for a in A for t in a])
+    ref = copy.deepcopy(rl)
+    for ag in ref.agents:
+        ag.critic_opt = None
+    opts = [torch.optim.Adam(ag.critic_model.parameters(), lr=ag.lr, eps=1e-7) for ag in ref.agents]
+    for b in batches:
+        rl.train_on_batch(*b)
+        _reference_order_update(ref, *b, opts)
+        for ag, bg in zip(rl.agents, ref.agents):
+            for net in ("actor_model", "critic_model"):
+                for p, q in zip(getattr(ag, net).parameters(), getattr(bg, net).parameters()):
+                    torch.testing.assert_close(p, q, rtol=1e-4, atol=2e-6)
+    assert float(rl.agents[0].critic_opt.step_t) == 3.0 and len(rl.agents[2].c_loss) == 3

@@ -24,7 +24,8 @@ A = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
 st = eng._net_state(S)
 acts = [A[0][0], A[0][1], A[1][0], A[1][1], A[2][0], A[2][1]]
 a0 = rl.agents[0]
-cs = RL._level_adjacencies(st)
+cs = {}
+ain = rl._actor_in(st)
 
 
 def count(tag, fn, detail=False):
@@ -40,33 +41,34 @@ def count(tag, fn, detail=False):
             print("      ", c, k[:100])
 
 
-def critic_fb():
-    for p in a0.critic_model.parameters():
-        p.grad = None
-    RL.critic_forward_grouped(a0.critic_model, st + acts, cs).pow(2).mean().backward()
+def critics_fb():
+    cps = [p for ag_ in rl.agents for p in ag_.critic_model.parameters()]
+    qs = RL.run_networks([RL._critic_steps(ag_.critic_model, st + acts) for ag_ in rl.agents], cs)
+    torch.autograd.grad(torch.cat(qs, 1).pow(2).mean(0).sum(), cps)
 
 
 def actor_fb():
     ap = list(a0.actor_model.parameters())
-    g, t = RL.actor_forward_grouped(a0.actor_model, rl._actor_in(st), cs)
-    q = RL.critic_forward_grouped(a0.critic_model, st + [g, t] + acts[2:], cs)
+    g, t = RL.run_networks([RL._actor_steps(a0.actor_model, ain)], cs)[0]
+    q = RL.run_networks([RL._critic_steps(a0.critic_model, st + [g, t] + acts[2:])], cs)[0]
     grads = torch.autograd.grad(-q.mean(), ap, allow_unused=True)
     for p, g_ in zip(ap, grads):
         p.grad = g_
 
 
 with torch.no_grad():
-    count("actor forward (no grad)", lambda: RL.actor_forward_grouped(a0.actor_model, rl._actor_in(st), cs), True)
-    count("critic forward (no grad)", lambda: RL.critic_forward_grouped(a0.critic_model, st + acts, cs), True)
-count("critic forward + backward", critic_fb, True)
+    count("actor forward (no grad)", lambda: RL.run_networks([RL._actor_steps(a0.actor_model, ain)], cs), True)
+    count("3 actors forward together (no grad)", lambda: RL.run_networks([RL._actor_steps(ag_.actor_model, ain) for ag_ in rl.agents], cs))
+    count("critic forward (no grad)", lambda: RL.run_networks([RL._critic_steps(a0.critic_model, st + acts)], cs), True)
+    count("3 critics forward together (no grad)", lambda: RL.run_networks([RL._critic_steps(ag_.critic_model, st + acts) for ag_ in rl.agents], cs))
+count("3 critics forward + backward together", critics_fb, True)
 count("actor + critic forward, backward to the actor", actor_fb, True)
-cp = list(a0.critic_model.parameters())
-count("clip (critic)", lambda: RL._clip_each(cp))
-count("critic Adam step", lambda: a0.critic_opt.step())
+cp = [p for ag_ in rl.agents for p in ag_.critic_model.parameters()]
+count("clip (3 critics)", lambda: RL._clip_each(cp))
+count("Adam step (3 critics together)", lambda: RL.SharedStepAdam.step_together([ag_.critic_opt for ag_ in rl.agents]))
 ap = list(a0.actor_model.parameters())
 count("clip (actor)", lambda: RL._clip_each(ap))
 count("actor fresh-Adam step", lambda: RL._fresh_adam_step(ap, 1e-4, 1e-7))
-count("level adjacencies", lambda: RL._level_adjacencies(st))
 A3 = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
 nst = [eng._net_state(ns) for ns in NS]
-count("whole update", lambda: rl.train_on_batch(st, nst, A3, R))
+count("whole update", lambda: rl.train_on_batch(st, nst, A3, R), True)
