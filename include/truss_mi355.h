@@ -315,6 +315,15 @@ typedef struct truss_gcn_layer_args {
 
 int truss_gcn_layer(const truss_gcn_layer_args_t *args, void *stream);
 
+/* A whole LEVEL of GCN layers in one launch: layers[i] as for truss_gcn_layer, for n_layers layers that do not depend on each other
+ * -- the layers of one depth of the reference's actor / critic graphs (truss2D_RL.py:86-103, 116-133), of one network or of
+ * several.  replaces: the forward passes of the MADDPG update (truss2D_RL.py:561-629: 19 network passes of 13 / 21 GCN layers at
+ * batch 32), which are bound by their kernel count when run layer by layer.  Grid = (row tiles, layers, 32-column blocks).
+ * float32 product only (w_bf16x3 = NULL, accumulate = 0), n_nodes <= 128 (dense: <= 64), any mix of shapes within one call.
+ *   x_agg  NULL, or n_layers pointers (entries may be NULL): where given, the kernel also stores X' = A X of that layer,
+ *          [n_batch * n_nodes][k_in] contiguous -- what the backward pass of the layer needs (dW = dZ^T X'). */
+int truss_gcn_level(const truss_gcn_layer_args_t *layers, int32_t n_layers, float *const *x_agg, void *stream);
+
 /* w [c_out <= 224][k_in] float32 -> w_bf16x3 [3][224][kp] bfloat16 bit patterns (kp = (k_in + 15) & ~15; rows >= c_out and columns >=
  * k_in are written as zeros: the layer kernel reads whole 224 x 16 slabs by LDS-DMA): the exact
  * three-term split the bf16x3 path of truss_gcn_layer reads.  Once per weight version; device pointers, 16-byte aligned output. */

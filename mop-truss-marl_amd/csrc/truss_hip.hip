@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <type_traits>
 
 #include "../../include/truss_mi355.h"
@@ -636,6 +637,7 @@ extern "C" int truss_debug_stamps(unsigned long long *out16) {
 #endif
 
 #include "truss_gcn.h"
+#include "truss_gcn_level.h"
 
 #include "truss_front.h"
 extern "C" int truss_front(const truss_front_args_t *a, void *stream) {

@@ -1,6 +1,6 @@
 // truss_torch_ops.cpp -- PyTorch custom operators in front of the C ABI of include/truss_mi355.h.
 //
-//   torch.ops.truss_mi355.step / rollout / obs / front / gcn_aggregate / gcn_aggregate_sparse / gcn_layer
+//   torch.ops.truss_mi355.step / rollout / obs / front / gcn_aggregate / gcn_aggregate_sparse / gcn_layer / gcn_level
 //
 // The reference's hot path runs inside TensorFlow ops on its side of the loop (truss2D_RL.py:328-354); here the env
 // step itself is an operator of the host framework: tensors in, tensors mutated in place, launched on the stream the
@@ -13,6 +13,7 @@
 #include <ATen/ATen.h>
 
 #include <array>
+#include <vector>
 #include <string>
 
 #include "../../include/truss_mi355.h"
@@ -29,6 +30,7 @@ struct Backend {
                     int32_t, void *) = nullptr;
   int (*gcn_layer)(const truss_gcn_layer_args_t *, void *) = nullptr;
   int (*gcn_split)(const float *, int32_t, int32_t, uint16_t *, void *) = nullptr;
+  int (*gcn_level)(const truss_gcn_layer_args_t *, int32_t, float *const *, void *) = nullptr;
   const char *(*last_error)(void) = nullptr;
   bool device = false;   // true: the HIP library (tensors must be on a cuda device)
 };
@@ -272,6 +274,46 @@ void gcn_layer(int64_t lib, int64_t stream, const at::Tensor &x, const at::Tenso
 void gcn_layer_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &, const OT &, const at::Tensor &, const OT &, const at::Tensor &,
                     int64_t, bool, const OT &) {}
 
+// a whole level of GCN layers in one launch: out[i] = act[i](adj[i] @ (x[i] @ w[i]^T) + bias[i]); x_agg (empty, or one tensor per
+// layer) receives adj[i] @ x[i] == truss_gcn_level
+void gcn_level(int64_t lib, int64_t stream, at::TensorList x, at::TensorList adj, at::TensorList w, at::TensorList bias, at::TensorList out,
+               at::TensorList x_agg, at::IntArrayRef act) {
+  const Backend &b = backend(lib);
+  TORCH_CHECK(b.gcn_level, "truss_mi355: the bound native library has no truss_gcn_level");
+  const size_t L = x.size();
+  TORCH_CHECK(adj.size() == L && w.size() == L && bias.size() == L && out.size() == L && act.size() == L && (x_agg.empty() || x_agg.size() == L),
+              "truss_mi355: gcn_level takes one entry per layer in every list");
+  std::vector<truss_gcn_layer_args_t> args(L);
+  std::vector<float *> xa(L, nullptr);
+  for (size_t i = 0; i < L; ++i) {
+    TORCH_CHECK(x[i].dim() == 3 && out[i].dim() == 3 && w[i].dim() == 2, "truss_mi355: x [B, N, K], w [C, K], out [B, N, C]");
+    const int64_t B = x[i].size(0), N = x[i].size(1), K = x[i].size(2), C = w[i].size(0);
+    TORCH_CHECK(w[i].size(1) == K && out[i].size(0) == B && out[i].size(1) == N && out[i].size(2) == C, "truss_mi355: gcn_level shapes do not match");
+    TORCH_CHECK((adj[i].dim() == 2 || adj[i].dim() == 3) && adj[i].size(-1) == N && adj[i].size(-2) == N && (adj[i].dim() == 2 || adj[i].size(0) == B),
+                "truss_mi355: adj must be [N, N] or [B, N, N]");
+    truss_gcn_layer_args_t &a = args[i];
+    a = truss_gcn_layer_args_t{};
+    a.struct_size = sizeof a;
+    a.n_batch = (int32_t)B;
+    a.n_nodes = (int32_t)N;
+    a.k_in = (int32_t)K;
+    a.c_out = (int32_t)C;
+    a.act = (int32_t)act[i];
+    a.x = ptr<const float>(b, x[i], at::kFloat, "x");
+    a.adj = ptr<const float>(b, adj[i], at::kFloat, "adj");
+    a.a_batch_stride = adj[i].dim() == 3 ? N * N : 0;
+    a.w = ptr<const float>(b, w[i], at::kFloat, "w");
+    a.bias = ptr<const float>(b, bias[i], at::kFloat, "bias", C);
+    a.out = ptr<float>(b, out[i], at::kFloat, "out");
+    if (!x_agg.empty()) {
+      TORCH_CHECK(x_agg[i].numel() == B * N * K, "truss_mi355: x_agg[i] must hold B * N * K elements");
+      xa[i] = ptr<float>(b, x_agg[i], at::kFloat, "x_agg");
+    }
+  }
+  check_rc(b, b.gcn_level(args.data(), (int32_t)L, x_agg.empty() ? nullptr : xa.data(), (void *)stream), "truss_gcn_level");
+}
+void gcn_level_meta(int64_t, int64_t, at::TensorList, at::TensorList, at::TensorList, at::TensorList, at::TensorList, at::TensorList, at::IntArrayRef) {}
+
 // w [C, K] float32 -> out [3, 224, KP] int16 (bfloat16 bit patterns, zero rows / columns beyond C / K): the exact three-term split of the bf16x3 path == truss_gcn_split_w
 void gcn_split_w(int64_t lib, int64_t stream, const at::Tensor &w, const at::Tensor &out) {
   const Backend &b = backend(lib);
@@ -287,7 +329,7 @@ void gcn_split_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &) {}
 
 // Bind the entry points of a loaded native library (addresses from ctypes) under a small index.
 extern "C" int truss_torch_bind(int lib, void *step_fn, void *rollout_fn, void *obs_fn, void *front_fn, void *gcn_fn, void *gcn_sparse_fn,
-                                void *gcn_layer_fn, void *gcn_split_fn, void *last_error_fn, int is_device) {
+                                void *gcn_layer_fn, void *gcn_split_fn, void *gcn_level_fn, void *last_error_fn, int is_device) {
   if (lib < 0 || lib >= (int)g_backends.size() || !step_fn) return -1;
   Backend &b = g_backends[lib];
   b.step = (decltype(b.step))step_fn;
@@ -298,6 +340,7 @@ extern "C" int truss_torch_bind(int lib, void *step_fn, void *rollout_fn, void *
   b.gcn_sparse = (decltype(b.gcn_sparse))gcn_sparse_fn;
   b.gcn_layer = (decltype(b.gcn_layer))gcn_layer_fn;
   b.gcn_split = (decltype(b.gcn_split))gcn_split_fn;
+  b.gcn_level = (decltype(b.gcn_level))gcn_level_fn;
   b.last_error = (decltype(b.last_error))last_error_fn;
   b.device = is_device != 0;
   return 0;
@@ -324,6 +367,7 @@ TORCH_LIBRARY(truss_mi355, m) {
   m.def("gcn_layer(int lib, int stream, Tensor x, Tensor adj, Tensor? nbr, Tensor w, Tensor? bias, Tensor(a!) out, int act, bool accumulate, "
         "Tensor? w_split) -> ()");
   m.def("gcn_split_w(int lib, int stream, Tensor w, Tensor(a!) out) -> ()");
+  m.def("gcn_level(int lib, int stream, Tensor[] x, Tensor[] adj, Tensor[] w, Tensor[] bias, Tensor(a!)[] out, Tensor(b!)[] x_agg, int[] act) -> ()");
 }
 TORCH_LIBRARY_IMPL(truss_mi355, CPU, m) {   // the emulator library of the test-suite binds here
   m.impl("step", step);
@@ -334,6 +378,7 @@ TORCH_LIBRARY_IMPL(truss_mi355, CPU, m) {   // the emulator library of the test-
   m.impl("gcn_aggregate_sparse", gcn_aggregate_sparse);
   m.impl("gcn_layer", gcn_layer);
   m.impl("gcn_split_w", gcn_split_w);
+  m.impl("gcn_level", gcn_level);
 }
 TORCH_LIBRARY_IMPL(truss_mi355, CUDA, m) {  // = HIP on ROCm: the product library
   m.impl("step", step);
@@ -344,6 +389,7 @@ TORCH_LIBRARY_IMPL(truss_mi355, CUDA, m) {  // = HIP on ROCm: the product librar
   m.impl("gcn_aggregate_sparse", gcn_aggregate_sparse);
   m.impl("gcn_layer", gcn_layer);
   m.impl("gcn_split_w", gcn_split_w);
+  m.impl("gcn_level", gcn_level);
 }
 TORCH_LIBRARY_IMPL(truss_mi355, Meta, m) {  // tracing: every operator only mutates its outputs
   m.impl("step", step_meta);
@@ -354,4 +400,5 @@ TORCH_LIBRARY_IMPL(truss_mi355, Meta, m) {  // tracing: every operator only muta
   m.impl("gcn_aggregate_sparse", gcn_sparse_meta);
   m.impl("gcn_layer", gcn_layer_meta);
   m.impl("gcn_split_w", gcn_split_meta);
+  m.impl("gcn_level", gcn_level_meta);
 }

@@ -150,13 +150,15 @@ class multimodes_critic(nn.Module):
 # summation order (tests/test_master_rl.py::test_grouped_forward_matches_layerwise: outputs <= 1e-5, gradients <= 1e-4 of their
 # scale).
 
-_LEVEL_FORWARD = None      # optional accelerator: callable(groups, xs, ws, bs) -> ([out_g], [xagg_g]) or None (truss_mi355.marl sets it)
+_LEVEL_FORWARD = {}        # device type -> callable(groups, xs, ws, bs, want_grad) -> ([out_g], [X'_g]) or None (truss_mi355.marl.level_forward)
 
 
-def set_level_forward(fn):
-    """Install (or, with None, remove) the fused level-forward; see `_GcnLevel.forward` for its contract."""
-    global _LEVEL_FORWARD
-    _LEVEL_FORWARD = fn
+def set_level_forward(fn, device_type="cuda"):
+    """Install (or, with None, remove) the fused level-forward for tensors of `device_type`; see `_GcnLevel.forward` for its contract."""
+    if fn is None:
+        _LEVEL_FORWARD.pop(device_type, None)
+    else:
+        _LEVEL_FORWARD[device_type] = fn
 
 
 class _Group:
@@ -180,18 +182,19 @@ def _adj_stack(adjs, B, N, cache=None):
 
 
 class _GcnLevel(torch.autograd.Function):
-    """apply(groups, *xs, *ws, *bs) -> one tensor [n_g, B, N, C] per group (see the section comment)."""
+    """apply((groups, want_grad), *xs, *ws, *bs) -> one tensor [n_g, B, N, C] per group (see the section comment)."""
 
     @staticmethod
-    def forward(ctx, groups, *tensors):
+    def forward(ctx, plan, *tensors):
+        groups, want_grad = plan           # want_grad: decided by the caller (inside forward the grad mode is always off)
         L = len(tensors) // 3
         xs, ws, bs = tensors[:L], tensors[L:2 * L], tensors[2 * L:]
-        want_grad = any(ctx.needs_input_grad[1:])
         outs = xaggs = None
-        if _LEVEL_FORWARD is not None and xs[0].is_cuda:
-            fused = _LEVEL_FORWARD(groups, xs, ws, bs, want_grad)
-            if fused is not None:
-                outs, xaggs = fused
+        fused = _LEVEL_FORWARD.get(xs[0].device.type)
+        if fused is not None:
+            res = fused(groups, xs, ws, bs, want_grad)
+            if res is not None:
+                outs, xaggs = res
         if outs is None:
             outs, xaggs = [], []
             for g in groups:
@@ -208,6 +211,12 @@ class _GcnLevel(torch.autograd.Function):
         ctx.groups, ctx.L = groups, L
         if want_grad:
             ctx.save_for_backward(*outs, *xaggs, *ws)
+            # a group none of whose inputs asks for a gradient (frozen networks evaluated alongside, layers on replayed inputs whose
+            # kernels are not trained in this pass): nothing flows back through it, nothing downstream stacks gradients for it
+            need = ctx.needs_input_grad
+            frozen = [o for g, o in zip(groups, outs) if not any(need[1 + i] or need[1 + L + i] or need[1 + 2 * L + i] for i in g.idx)]
+            if frozen:
+                ctx.mark_non_differentiable(*frozen)
         return tuple(outs)
 
     @staticmethod
@@ -219,7 +228,9 @@ class _GcnLevel(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx, dw, db = [None] * L, [None] * L, [None] * L
         for gi, g in enumerate(groups):
-            if douts[gi] is None:
+            need_w = any(need[1 + L + i] or need[1 + 2 * L + i] for i in g.idx)
+            need_x = any(need[1 + i] for i in g.idx)
+            if douts[gi] is None or not (need_w or need_x):
                 continue
             n, (B, N, K) = len(g.idx), g.shape
             o = outs[gi]
@@ -227,12 +238,12 @@ class _GcnLevel(torch.autograd.Function):
             d = douts[gi].contiguous()
             dz = (torch.ops.aten.threshold_backward(d, o, 0.0) if g.act == "relu" else
                   torch.ops.aten.sigmoid_backward(d, o) if g.act == "sigmoid" else d).view(n, B * N, C)
-            if any(need[1 + L + i] or need[1 + 2 * L + i] for i in g.idx):
+            if need_w:
                 for i, piece in zip(g.idx, torch.bmm(dz.transpose(1, 2), xaggs[gi]).unbind(0)):     # dW = dZ^T X'   [n, C, K]
                     dw[i] = piece
                 for i, piece in zip(g.idx, dz.sum(dim=1).unbind(0)):
                     db[i] = piece
-            if any(need[1 + i] for i in g.idx):
+            if need_x:
                 gw = torch.bmm(dz, torch.stack([ws[i] for i in g.idx]))                             # dZ W           [n, B N, K]
                 gx = torch.bmm(g.a.transpose(1, 2), gw.view(n * B, N, K)).view(n, B, N, K)         # A^T (dZ W)
                 for i, piece in zip(g.idx, gx.unbind(0)):
@@ -244,54 +255,80 @@ def gcn_level(reqs, cache=None):
     """reqs: [(GCNConv layer, x [B,N,K], adjacency [B,N,N] or [1,N,N], activation)] -> [act(adj @ x @ W^T + b)] in request order.
     Layers of equal shapes and activation form a group (one set of batched GEMMs forward and backward)."""
     by_key = {}
+    live = torch.is_grad_enabled()
     for i, (layer, x, adj, act) in enumerate(reqs):
-        by_key.setdefault((tuple(x.shape), layer.lin.out_features, act), []).append(i)
+        trains = live and (x.requires_grad or layer.lin.weight.requires_grad)      # frozen passes evaluated alongside: groups of their own
+        by_key.setdefault((tuple(x.shape), layer.lin.out_features, act, trains), []).append(i)
     groups = []
-    for (shape, _, act), idx in by_key.items():
+    for (shape, _, act, _), idx in by_key.items():
         adjs = [reqs[i][2] for i in idx]
         groups.append(_Group(idx, act, _adj_stack(adjs, shape[0], shape[1], cache), adjs, shape))
-    outs = _GcnLevel.apply(groups, *[r[1] for r in reqs], *[r[0].lin.weight for r in reqs], *[r[0].bias for r in reqs])
+    tensors = [r[1] for r in reqs] + [r[0].lin.weight for r in reqs] + [r[0].bias for r in reqs]
+    want_grad = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+    outs = _GcnLevel.apply((groups, want_grad), *tensors)
     res = [None] * len(reqs)
     for g, o in zip(groups, outs):
         # unbind, not o[i]: its backward is ONE stack of the pieces' gradients; every select's backward is a fill, a copy and an add
-        for i, piece in zip(g.idx, o.unbind(0)):
+        # (a single layer: a view, whose backward is a view)
+        for i, piece in zip(g.idx, (o.squeeze(0),) if len(g.idx) == 1 else o.unbind(0)):
             res[i] = piece
     return res
+
+
+class _Frozen:
+    """a GCNConv seen through detached parameters: a network that is evaluated WITHOUT gradients in the same `run_networks` call as
+    one that is trained (its layers form groups of their own, which the level operation marks non-differentiable)"""
+
+    class _Lin:
+        __slots__ = ("weight", "out_features")
+
+    __slots__ = ("lin", "bias")
+
+    def __init__(self, layer):
+        self.lin = _Frozen._Lin()
+        self.lin.weight, self.lin.out_features = layer.lin.weight.detach(), layer.lin.out_features
+        self.bias = layer.bias.detach()
 
 
 def _ready(layers):
     return not any(isinstance(L.lin.weight, nn.parameter.UninitializedParameter) for L in layers)
 
 
-def _actor_steps(a, inputs):
-    """multimodes_actor.forward as a generator: yields the requests of one level, receives that level's outputs"""
+def _actor_steps(a, inputs, frozen=False):
+    """multimodes_actor.forward as a generator: yields the requests of one level, receives that level's outputs.
+    frozen: evaluate through detached parameters (no gradient is wanted from this pass)"""
     x_n, A_n, A_s, A_n_ts, A_n_cs, x_p, A_p = inputs
-    o = yield [(a.gcn_l1_1, x_n, A_n, "relu"), (a.gcn_l1_2, x_n, A_n, "relu"), (a.gcn_l1_3, x_n, A_n, "relu"),
-               (a.gcn_l1_4, x_p, A_p, "relu")]
+    f = _Frozen if frozen else (lambda layer: layer)
+    o = yield [(f(a.gcn_l1_1), x_n, A_n, "relu"), (f(a.gcn_l1_2), x_n, A_n, "relu"), (f(a.gcn_l1_3), x_n, A_n, "relu"),
+               (f(a.gcn_l1_4), x_p, A_p, "relu")]
     x_1_4 = _tile_pool(o[3].sum(dim=1), x_n.shape[1])                                                # GlobalSumPool, tiled
-    o = yield [(a.gcn_l2_1, o[0], A_n, "relu"), (a.gcn_l2_2, o[1], A_n_ts, "relu"), (a.gcn_l2_3, o[1], A_n_cs, "relu"),
-               (a.gcn_l2_4, o[2], A_s, "relu"), (a.gcn_l2_5, x_1_4, A_n, "relu")]
+    o = yield [(f(a.gcn_l2_1), o[0], A_n, "relu"), (f(a.gcn_l2_2), o[1], A_n_ts, "relu"), (f(a.gcn_l2_3), o[1], A_n_cs, "relu"),
+               (f(a.gcn_l2_4), o[2], A_s, "relu"), (f(a.gcn_l2_5), x_1_4, A_n, "relu")]
     x_3 = torch.stack(o).sum(dim=0)
-    o = yield [(a.gcn_l3_1, x_3, A_n, "relu"), (a.gcn_l3_2, x_3, A_s, "relu")]
-    o = yield [(a.gcn_l4_1, o[0], A_n, "sigmoid"), (a.gcn_l4_2, o[1], A_n, "sigmoid")]
+    o = yield [(f(a.gcn_l3_1), x_3, A_n, "relu"), (f(a.gcn_l3_2), x_3, A_s, "relu")]
+    o = yield [(f(a.gcn_l4_1), o[0], A_n, "sigmoid"), (f(a.gcn_l4_2), o[1], A_n, "sigmoid")]
     return o[0], o[1]
 
 
-def _critic_steps(c, inputs):
-    """multimodes_critic.forward as a generator (see _actor_steps)"""
+def _critic_steps(c, inputs, frozen=False):
+    """multimodes_critic.forward as a generator (see _actor_steps).  frozen: the critic's own parameters are not trained by this pass
+    (the actor update differentiates THROUGH the critic, with respect to the action inputs only): its layers are seen through
+    detached parameters, so that only the layers on the path from those inputs take part in the backward pass."""
     x_n, A_n, A_s, A_n_ts, A_n_cs, mask, x_p, A_p, self_g, self_t, other_g1, other_t1, other_g2, other_t2 = inputs
+    f = _Frozen if frozen else (lambda layer: layer)
     acts = [self_g, self_t, other_g1, other_t1, other_g2, other_t2]
-    o = yield ([(c.l1[i], x_n, A_n, "relu") for i in range(3)] + [(c.l1[3], x_p, A_p, "relu")] +
-               [(c.l1[4 + i], a_, A_n, "relu") for i, a_ in enumerate(acts)])
+    o = yield ([(f(c.l1[i]), x_n, A_n, "relu") for i in range(3)] + [(f(c.l1[3]), x_p, A_p, "relu")] +
+               [(f(c.l1[4 + i]), a_, A_n, "relu") for i, a_ in enumerate(acts)])
     x_1_4 = _tile_pool(o[3].sum(dim=1), x_n.shape[1])
     xs = [o[0], o[1], o[1], o[2]] + list(o[4:10]) + [x_1_4]
     adjs = [A_n, A_n_ts, A_n_cs, A_s] + [A_n] * 7
-    o = yield [(c.l2[i], xs[i], adjs[i], "relu") for i in range(11)]
+    o = yield [(f(c.l2[i]), xs[i], adjs[i], "relu") for i in range(11)]
     # 11 x GlobalSumPool -> Concatenate, as one reduction: [B, 11, N, C] summed over the nodes = the 11 pooled vectors side by side
     q = torch.stack(o, dim=1).sum(dim=2).flatten(1)
-    q = torch.relu(c.dense_1(q))
-    q = torch.relu(c.dense_2(q))
-    return c.dense_out(q)
+    dense = (lambda m, t: nn.functional.linear(t, m.weight.detach(), m.bias.detach())) if frozen else (lambda m, t: m(t))
+    q = torch.relu(dense(c.dense_1, q))
+    q = torch.relu(dense(c.dense_2, q))
+    return dense(c.dense_out, q)
 
 
 def run_networks(gens, cache=None):
@@ -598,11 +635,8 @@ class MADDPG:
         flat = lambda order: [A[order[0]][0], A[order[0]][1], A[order[1]][0], A[order[1]][1], A[order[2]][0], A[order[2]][1]]
         orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]          # (self, other1, other2) per agent (:561-563)
         self._ensure_ready(S, flat(orders[0]))
-        # Passes that do not depend on each other go through `run_networks` TOGETHER (one operation per level for all of them); what
-        # must stay apart (a pass with and one without gradients) runs side by side: inside a hipGraph capture (truss_mi355/marl.py)
-        # each such branch goes to its own stream, forked from and joined back to the capturing stream, so that the replayed graph
-        # has parallel branches.  Eager runs (warm-up, CPU tests, the per-env reference loop) keep one stream: same operations.
-        par = self._branches()
+        # Passes that do not depend on each other go through `run_networks` TOGETHER: one operation per level for all of them (on the
+        # GPU one launch), including passes WITHOUT gradients next to one that is trained (`frozen`).
         agents = self.agents
         pair = lambda preds, o: [preds[o[0]][0], preds[o[0]][1], preds[o[1]][0], preds[o[1]][1], preds[o[2]][0], preds[o[2]][1]]
         cn, cs = {}, {}                  # per-minibatch caches of the stacked adjacencies (data only)
@@ -639,22 +673,15 @@ class MADDPG:
         # The actor updates stay one after the other: agent i's loss re-evaluates ALL three actors (:617-629), i.e. it sees the
         # weights agents < i have just stepped to -- one collective per actor.  (The other two actors' passes carry no gradient
         # that is asked for -- autograd.grad is taken with respect to agent i's parameters only -- so they run without a graph.)
-        def no_grad_eval(js, cache):
-            with torch.no_grad():
-                return run_networks([_actor_steps(agents[j].actor_model, self._actor_in(S)) for j in js], cache)
-
         frozen = {}          # no-gradient evaluations that are still valid: actor j's weights only change in iteration j
         for i, ag in enumerate(agents):
             o = orders[i]
             todo = [j for j in range(len(agents)) if j != i and j not in frozen]
-            fns = [lambda c: run_networks([_actor_steps(ag.actor_model, self._actor_in(S))], c)[0]]
-            if todo:
-                fns.append(lambda c: no_grad_eval(todo, c))
-            res = par(fns, cs)
-            if todo:
-                frozen.update(zip(todo, res[1]))
+            res = run_networks([_actor_steps(ag.actor_model, self._actor_in(S))] +
+                               [_actor_steps(agents[j].actor_model, self._actor_in(S), frozen=True) for j in todo], cs)
+            frozen.update(zip(todo, res[1:]))
             preds = [res[0] if j == i else frozen[j] for j in range(len(agents))]
-            q = run_networks([_critic_steps(ag.critic_model, S + pair(preds, o))], cs)[0]
+            q = run_networks([_critic_steps(ag.critic_model, S + pair(preds, o), frozen=True)], cs)[0]
             actor_loss = -q.mean()
             ap = list(ag.actor_model.parameters())
             for p in ap:
@@ -668,34 +695,6 @@ class MADDPG:
             # agent i's weights have just changed: an evaluation of actor i taken before this step must not be reused (the others'
             # stay valid: agents > i have not stepped yet, evaluations of agents < i were taken after their steps)
             frozen = {j: v for j, v in frozen.items() if j != i}
-
-    def _branches(self):
-        """callable(list of thunks(cache), cache) -> list of results; on side streams when the current CUDA stream is being captured.
-        Every branch gets its own view of the cache (reads fall through to the caller's, writes stay with the branch until the
-        join): an entry another branch computes on ITS stream is never read by a sibling."""
-        import collections
-        dev = self.device
-        capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        if capturing and getattr(self, "_side_streams", None) is None:
-            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
-
-        def run(fns, cache):
-            views = [collections.ChainMap({}, cache) for _ in fns]
-            if not capturing or len(fns) == 1:
-                outs = [f(v) for f, v in zip(fns, views)]
-            else:
-                cur = torch.cuda.current_stream(dev)
-                outs = []
-                for st, f, v in zip(self._side_streams, fns, views):
-                    st.wait_stream(cur)                  # fork: the branch sees everything enqueued so far
-                    with torch.cuda.stream(st):
-                        outs.append(f(v))
-                for st in self._side_streams[:len(fns)]:
-                    cur.wait_stream(st)                  # join
-            for v in views:
-                cache.update(v.maps[0])
-            return outs
-        return run
 
     def sync_parameters(self, src=0):
         """Data-parallel start: every rank takes rank `src`'s actor / critic / target weights (one broadcast

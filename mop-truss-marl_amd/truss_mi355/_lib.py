@@ -101,6 +101,8 @@ class TrussLib:
         d.truss_gcn_aggregate.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
         d.truss_gcn_layer.restype = C.c_int
         d.truss_gcn_layer.argtypes = [_vp, _vp]
+        d.truss_gcn_level.restype = C.c_int
+        d.truss_gcn_level.argtypes = [_vp, C.c_int32, _vp, _vp]
         d.truss_gcn_split_w.restype = C.c_int
         d.truss_gcn_split_w.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp]
         d.truss_gcn_aggregate_sparse.restype = C.c_int

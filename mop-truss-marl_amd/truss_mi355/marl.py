@@ -173,6 +173,41 @@ def gcn_layer(lib, x, adj, w, bias, act, nbr=None, out=None, accumulate=False, p
     return out
 
 
+def level_forward(lib):
+    """The fused forward of a whole level of GCN layers (`truss_gcn_level`, csrc/truss_gcn_level.h: one launch for every layer of
+    every group) in the shape truss2D_RL._GcnLevel asks for: callable(groups, xs, ws, bs, want_grad) -> ([out_g [n, B, N, C]],
+    [X'_g [n, B N, K] or None]), or None when a shape is outside the kernel's envelope (the caller then evaluates the level with
+    batched library GEMMs).  Installed by BatchedMARL on the GPU (`truss2D_RL.set_level_forward`)."""
+    from . import ops
+    code = {None: 0, "relu": 1, "sigmoid": 2}
+
+    def run(groups, xs, ws, bs, want_grad):
+        X, ADJ, W, BIAS, OUT, XAGG, ACT, outs, xaggs = [], [], [], [], [], [], [], [], []
+        for g in groups:
+            n, (B, N, K), C = len(g.idx), g.shape, ws[g.idx[0]].shape[0]
+            if N > 64 or C > 224 or xs[g.idx[0]].dtype != torch.float32:
+                return None
+            o = torch.empty((n, B, N, C), dtype=torch.float32, device=xs[g.idx[0]].device)
+            xa = torch.empty((n, B * N, K), dtype=torch.float32, device=o.device) if want_grad else None
+            for j, i in enumerate(g.idx):
+                a = g.adjs[j]
+                if a.dim() == 3 and (a.shape[0] == 1 or a.stride(0) == 0):
+                    a = a[0]
+                X.append(xs[i].detach().contiguous())
+                ADJ.append(a.contiguous())
+                W.append(ws[i].detach())
+                BIAS.append(bs[i].detach())
+                OUT.append(o[j])
+                if want_grad:
+                    XAGG.append(xa[j])
+                ACT.append(code[g.act])
+            outs.append(o)
+            xaggs.append(xa)
+        ops.call(ops.namespace().gcn_level, ops.bind(lib), ops.stream_of(X[0].device), X, ADJ, W, BIAS, OUT, XAGG, ACT)
+        return outs, xaggs
+    return run
+
+
 def gcn_layer_supported(n_nodes, c_out, nbr):
     """shapes the fused layer kernel takes (include/truss_mi355.h); anything else goes through library GEMM + aggregation kernels"""
     return c_out <= 224 and n_nodes <= 256 and ((nbr is not None and nbr.shape[1] <= 16) or (nbr is None and n_nodes <= 64))
@@ -289,6 +324,9 @@ class BatchedMARL:
         self.envP = BatchedTruss(topo, self.cap, device=device, lib=lib)          # archive members under study
         self.envC = BatchedTruss(topo, 3 * self.cap, device=device, lib=lib)      # their candidates, agent-major
         self.lib, self.device = self.envP.lib, self.envP.device
+        if self.device.type == "cuda" and os.environ.get("TRUSS_LEVEL_FORWARD", "1") != "0":
+            import truss2D_RL
+            truss2D_RL.set_level_forward(level_forward(self.lib), "cuda")   # the update's forward passes: one launch per level
         dev, B, P, N, E = self.device, self.B, self.P, topo.N, topo.E
         A_n, mask = topo.normalized_adjacency()
         self.A_n = torch.tensor(A_n, device=dev)[None]

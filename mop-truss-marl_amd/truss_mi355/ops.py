@@ -1,6 +1,6 @@
 """torch.ops.truss_mi355.* -- the env step as PyTorch custom operators.
 
-`csrc/truss_torch_ops.cpp` registers `step`, `rollout`, `obs`, `front`, `gcn_aggregate`, `gcn_aggregate_sparse` and `gcn_layer` with the dispatcher
+`csrc/truss_torch_ops.cpp` registers `step`, `rollout`, `obs`, `front`, `gcn_aggregate`, `gcn_aggregate_sparse`, `gcn_layer` and `gcn_level` with the dispatcher
 (CPU / CUDA(=HIP) / Meta keys): tensors in, outputs mutated in place, launched on the stream the caller names,
 capturable in a hipGraph, traceable.  The operators do no arithmetic; they call the C ABI of the native library that
 `bind()` registered under an index -- the HIP product library, or (test-suite only) the CPU lane emulator.
@@ -30,7 +30,7 @@ def _load():
         torch.ops.load_library(OPS_LIB)              # runs the TORCH_LIBRARY registrations
         _dll = C.CDLL(OPS_LIB)                       # the same image: for truss_torch_bind
         _dll.truss_torch_bind.restype = C.c_int
-        _dll.truss_torch_bind.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int]
+        _dll.truss_torch_bind.argtypes = [C.c_int] + [C.c_void_p] * 10 + [C.c_int]
     return _dll
 
 
@@ -42,7 +42,7 @@ def bind(lib: "_lib.TrussLib") -> int:
         addr = lambda f: C.cast(f, C.c_void_p)
         rc = dll.truss_torch_bind(idx, addr(d.truss_step), addr(d.truss_rollout), addr(d.truss_obs), addr(d.truss_front),
                                   addr(d.truss_gcn_aggregate), addr(d.truss_gcn_aggregate_sparse), addr(d.truss_gcn_layer),
-                                  addr(d.truss_gcn_split_w), addr(d.truss_last_error),
+                                  addr(d.truss_gcn_split_w), addr(d.truss_gcn_level), addr(d.truss_last_error),
                                   1 if lib.backend == "hip" else 0)
         if rc != 0:
             raise _lib.TrussError("truss_torch_bind failed (more than 8 native libraries bound?)")

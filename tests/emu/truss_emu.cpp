@@ -418,6 +418,34 @@ extern "C" int truss_gcn_layer(const truss_gcn_layer_args_t *a, void *) {
   return TRUSS_OK;
 }
 
+// truss_gcn_level, CPU stand-in: the layers one after the other through the stand-in above, X' = A X stored where asked for
+extern "C" int truss_gcn_level(const truss_gcn_layer_args_t *layers, int32_t n_layers, float *const *x_agg, void *st) {
+  if (n_layers < 0 || (n_layers > 0 && !layers)) return tb_fail(TRUSS_EINVAL, "truss_gcn_level: bad argument");
+  for (int l = 0; l < n_layers; ++l) {
+    const truss_gcn_layer_args_t *a = layers + l;
+    if (a->struct_size != sizeof(truss_gcn_layer_args_t)) return tb_fail(TRUSS_EINVAL, "truss_gcn_level: bad argument block");
+    if (a->accumulate || a->w_bf16x3 || a->n_nodes > 128) return tb_fail(TRUSS_EUNSUPPORTED, "truss_gcn_level: shape / mode outside the kernel's envelope");
+    if (int rc = truss_gcn_layer(a, st)) return rc;
+    if (!x_agg || !x_agg[l]) continue;
+    const int N = a->n_nodes, K = a->k_in;
+    const long xs = a->x_row_stride ? a->x_row_stride : K;
+    for (int b = 0; b < a->n_batch; ++b) {
+      const float *A = a->adj + (size_t)b * a->a_batch_stride;
+      const float *X = a->x + (size_t)b * N * xs;
+      for (int i = 0; i < N; ++i)
+        for (int k = 0; k < K; ++k) {
+          float acc = 0.0f;
+          for (int t = 0; t < (a->nbr ? a->k_nbr : N); ++t) {
+            const int j = a->nbr ? a->nbr[i * a->k_nbr + t] : t;
+            if (j >= 0) acc += A[(size_t)i * N + j] * X[(size_t)j * xs + k];
+          }
+          x_agg[l][((size_t)b * N + i) * K + k] = acc;
+        }
+    }
+  }
+  return TRUSS_OK;
+}
+
 // the exact three-term bfloat16 split of the bf16x3 path (host restatement); the emulated layer itself sums in float32
 extern "C" int truss_gcn_split_w(const float *w, int32_t c_out, int32_t k_in, uint16_t *out, void *) {
   if (!w || !out || c_out < 1 || k_in < 1 || c_out > 224) return tb_fail(TRUSS_EINVAL, "truss_gcn_split_w: bad argument");

@@ -242,6 +242,74 @@ def test_gcn_layer_hip():
     _check_gcn_layer(tm.load(), "cuda")
 
 
+def _check_gcn_level(lib, device):
+    """the fused level forward (truss_gcn_level: every layer of a level, of several networks, in one launch) installed as the
+    forward of truss2D_RL's level operation: outputs and gradients of three merged critics + three merged actors against the
+    modules' own layer-by-layer float32 evaluation; the hook must really have run (every group, with and without gradients)."""
+    torch.manual_seed(2)
+    B, N, P, H = 32, 16, 20, 200
+    r = lambda *s: torch.rand(*s, device=device)
+    A = lambda n: torch.softmax(torch.randn(B, n, n, device=device), dim=-1)
+    S = [r(B, N, 13), A(N)[:1].expand(B, -1, -1), A(N), A(N), A(N), torch.ones(B, N, N, device=device), r(B, P, 4), A(P)]
+    ain = [S[0], S[1], S[2], S[3], S[4], S[6], S[7]]
+    acts = [t.requires_grad_() for t in (r(B, N, 2), r(B, N, 3), r(B, N, 2), r(B, N, 3), r(B, N, 2), r(B, N, 3))]
+    actors = [RL.multimodes_actor(H, 2, 3).to(device) for _ in range(3)]
+    critics = [RL.multimodes_critic(H, 64).to(device) for _ in range(3)]
+    with torch.no_grad():
+        for a, c in zip(actors, critics):
+            a(ain), c(S + acts)
+    fused = marl.level_forward(lib)
+    calls = []
+
+    def hook(groups, xs, ws, bs, want_grad):
+        res = fused(groups, xs, ws, bs, want_grad)
+        calls.append((len(groups), want_grad, res is not None))
+        return res
+
+    def loss(outs, qs):
+        return sum((k + 1.0) * (o[0].sum() + o[1].pow(2).sum()) for k, o in enumerate(outs)) + sum((k + 2.0) * q.pow(2).mean() for k, q in enumerate(qs))
+
+    RL.set_level_forward(hook, device)
+    try:
+        with torch.no_grad():
+            o_ng = RL.run_networks([RL._actor_steps(a, ain) for a in actors], {})
+        outs = RL.run_networks([RL._actor_steps(a, ain) for a in actors], {})
+        qs = RL.run_networks([RL._critic_steps(c, S + acts) for c in critics], {})
+        wrt = [p for n in actors + critics for p in n.parameters()] + acts
+        g_fused = torch.autograd.grad(loss(outs, qs), wrt)
+    finally:
+        RL.set_level_forward(None, device)
+    assert len(calls) == 4 + 4 + 2 and all(ok for _, _, ok in calls) and [w for _, w, _ in calls] == [False] * 4 + [True] * 6
+    ref_o, ref_q = [a(ain) for a in actors], [c(S + acts) for c in critics]
+    for o, o2, ref in zip(outs, o_ng, ref_o):
+        for x, x2, y in zip(o, o2, ref):
+            torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6)
+            torch.testing.assert_close(x2, y, rtol=2e-5, atol=2e-6)
+    for q, y in zip(qs, ref_q):
+        torch.testing.assert_close(q, y, rtol=2e-5, atol=2e-5)
+    for a, b in zip(torch.autograd.grad(loss(ref_o, ref_q), wrt), g_fused):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
+    # shapes outside the kernel's envelope are handed back (None), not computed wrongly
+    big = RL.GCNConv(8).to(device)
+    big(r(1, 80, 8), torch.eye(80, device=device)[None])
+    RL.set_level_forward(hook, device)
+    try:
+        with torch.no_grad():
+            got = RL.gcn_level([(big, r(2, 80, 8), torch.eye(80, device=device)[None], "relu")])[0]
+    finally:
+        RL.set_level_forward(None, device)
+    assert calls[-1][2] is False and got.shape == (2, 80, 8)
+
+
+def test_gcn_level_emulated():
+    _check_gcn_level(pc.emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_gcn_level_hip():
+    _check_gcn_level(tm.load(), "cuda")
+
+
 def test_sparse_aggregate_emulated():
     _check_sparse_aggregate(pc.emu_lib(), "cpu")
 

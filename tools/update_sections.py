@@ -50,7 +50,7 @@ def critics_fb():
 def actor_fb():
     ap = list(a0.actor_model.parameters())
     g, t = RL.run_networks([RL._actor_steps(a0.actor_model, ain)], cs)[0]
-    q = RL.run_networks([RL._critic_steps(a0.critic_model, st + [g, t] + acts[2:])], cs)[0]
+    q = RL.run_networks([RL._critic_steps(a0.critic_model, st + [g, t] + acts[2:], frozen=True)], cs)[0]
     grads = torch.autograd.grad(-q.mean(), ap, allow_unused=True)
     for p, g_ in zip(ap, grads):
         p.grad = g_
