@@ -209,6 +209,7 @@ class _GcnLevel(torch.autograd.Function):
                 outs.append(o.view(n, B, N, C))
                 xaggs.append(xa)
         ctx.groups, ctx.L = groups, L
+        ctx.set_materialize_grads(False)       # a group nothing flows back into arrives as None in backward, not as a tensor of zeros
         if want_grad:
             ctx.save_for_backward(*outs, *xaggs, *ws)
             # a group none of whose inputs asks for a gradient (frozen networks evaluated alongside, layers on replayed inputs whose
@@ -378,7 +379,8 @@ _seg_cache: dict = {}
 
 
 def _clip_each(params, max_norm=1.0):
-    """Keras `clipnorm`: every gradient tensor is clipped to L2 norm <= clipnorm on its own."""
+    """Keras `clipnorm`: every gradient tensor is clipped to L2 norm <= clipnorm on its own (in place, on p.grad; the update itself
+    clips the flat gradient vector: `_clip_flat`)."""
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
@@ -401,18 +403,37 @@ def _clip_each(params, max_norm=1.0):
     torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
 
+def _flat_grads(params):
+    """the gradients of `params` as ONE contiguous vector (the all-reduce buffer, and what the flat clip / Adam below work on)"""
+    return torch.cat([p.grad.reshape(-1) for p in params])
+
+
+def _clip_flat(flat, params, max_norm=1.0):
+    """`_clip_each` on the flat gradient vector of `params` (in place): every tensor's slice scaled to L2 norm <= max_norm."""
+    sizes = [p.numel() for p in params]
+    fac = torch.stack(torch._foreach_norm(list(flat.split(sizes)))).add_(1e-12).reciprocal_()
+    if max_norm != 1.0:
+        fac.mul_(max_norm)
+    fac.clamp_(max=1.0)
+    key = (tuple(sizes), flat.device)
+    seg = _seg_cache.get(key)
+    if seg is None:
+        seg = torch.repeat_interleave(torch.arange(len(sizes), device=flat.device), torch.tensor(sizes, device=flat.device))
+        _seg_cache[key] = seg
+    return flat.mul_(fac[seg])
+
+
 class SharedStepAdam:
-    """`torch.optim.Adam(params, lr, betas, eps)` for a parameter list that always steps together (a critic): ONE step counter on the
-    device and multi-tensor launches throughout, usable inside a hipGraph.  PyTorch's capturable Adam keeps a step tensor per
-    parameter, and dividing a tensor list by a list of 0-dim tensors falls off the multi-tensor path: two launches per parameter
-    tensor and step, 96 per critic update.  Same arithmetic: m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2;
-    p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)."""
+    """`torch.optim.Adam(params, lr, betas, eps)` for a parameter list that always steps together (the critics of a MADDPG): ONE step
+    counter on the device and the moments as two FLAT vectors, so that a step is a dozen element-wise launches whatever the number
+    of parameter tensors (144 for three critics), usable inside a hipGraph.  PyTorch's capturable Adam keeps a step tensor per
+    parameter and runs multi-tensor kernels of at most a few dozen tensors each: 35 launches for the same step.  Same arithmetic:
+    m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)."""
 
     def __init__(self, params, lr, eps=1e-8, betas=(0.9, 0.999)):
         self.params = list(params)
         self.lr, self.eps, (self.b1, self.b2) = float(lr), float(eps), betas
-        self.step_t, self.exp_avg, self.exp_avg_sq = None, None, None
-        self.n_steps = 0                 # host-side count of step calls (capture counts once): only compared between optimisers
+        self.step_t, self.exp_avg, self.exp_avg_sq = None, None, None      # 0-dim float64; flat float32 vectors
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -420,76 +441,56 @@ class SharedStepAdam:
 
     def state_tensors(self):
         """the optimiser's state as a flat list (empty before the first step): step counter, first moments, second moments"""
-        return [] if self.step_t is None else [self.step_t] + self.exp_avg + self.exp_avg_sq
+        return [] if self.step_t is None else [self.step_t, self.exp_avg, self.exp_avg_sq]
 
-    def step(self):
-        SharedStepAdam.step_together([self])
-
-    @staticmethod
     @torch.no_grad()
-    def step_together(opts):
-        """`step()` of every optimiser in `opts` as ONE set of multi-tensor launches.  The optimisers must have the same
-        hyper-parameters and must always have stepped together (the three critics of a MADDPG): their step counters then hold the
-        same number and the first one's bias corrections serve all."""
-        o0 = opts[0]
-        if any((o.lr, o.eps, o.b1, o.b2, o.n_steps) != (o0.lr, o0.eps, o0.b1, o0.b2, o0.n_steps) for o in opts):
-            raise RuntimeError("SharedStepAdam.step_together: optimisers differ in hyper-parameters or step count")
-        for o in opts:
-            if o.step_t is None:
-                o.step_t = torch.zeros((), dtype=torch.float64, device=o.params[0].device)   # float64: 1 - 0.999^t cancels badly in float32
-                o.exp_avg = [torch.zeros_like(p) for p in o.params]
-                o.exp_avg_sq = [torch.zeros_like(p) for p in o.params]
-            o.n_steps += 1
-        ps = [p for o in opts for p in o.params]
-        grads = [p.grad for p in ps]
-        if any(g is None for g in grads):
-            raise RuntimeError("SharedStepAdam: every parameter must have a gradient (the list steps together)")
-        m, v = [t for o in opts for t in o.exp_avg], [t for o in opts for t in o.exp_avg_sq]
-        torch._foreach_add_([o.step_t for o in opts], 1)
-        bc1 = 1 - torch.pow(o0.b1, o0.step_t)
-        bc2_sqrt = (1 - torch.pow(o0.b2, o0.step_t)).sqrt_().float()
-        torch._foreach_lerp_(m, grads, 1 - o0.b1)
-        torch._foreach_mul_(v, o0.b2)
-        torch._foreach_addcmul_(v, grads, grads, value=1 - o0.b2)
-        den = torch._foreach_sqrt(v)
-        torch._foreach_div_(den, bc2_sqrt)
-        torch._foreach_add_(den, o0.eps)
-        upd = torch._foreach_div(m, den)
-        torch._foreach_mul_(upd, (-o0.lr / bc1).float())
-        torch._foreach_add_(ps, upd)
+    def step(self, flat_grad=None):
+        """flat_grad: the (clipped) gradient of all parameters as one vector (`_flat_grads`); default: built from p.grad"""
+        ps = self.params
+        if flat_grad is None:
+            if any(p.grad is None for p in ps):
+                raise RuntimeError("SharedStepAdam: every parameter must have a gradient (the list steps together)")
+            flat_grad = _flat_grads(ps)
+        if self.step_t is None:
+            self.step_t = torch.zeros((), dtype=torch.float64, device=ps[0].device)   # float64: 1 - 0.999^t cancels badly in float32
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat_grad), torch.zeros_like(flat_grad)
+        m, v, g = self.exp_avg, self.exp_avg_sq, flat_grad
+        self.step_t += 1
+        bc1 = 1 - torch.pow(self.b1, self.step_t)
+        bc2_sqrt = (1 - torch.pow(self.b2, self.step_t)).sqrt_().float()
+        m.lerp_(g, 1 - self.b1)
+        v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+        upd = v.sqrt().div_(bc2_sqrt).add_(self.eps).reciprocal_().mul_(m).mul_((-self.lr / bc1).float())
+        torch._foreach_add_(ps, [u.view_as(p) for u, p in zip(upd.split([p.numel() for p in ps]), ps)])
 
 
-def _fresh_adam_step(params, lr, eps):
+def _fresh_adam_step(params, lr, eps, flat_grad=None):
     """`Adam(params, lr, eps=eps).step()` of an optimiser that is created for this one call (the reference builds a new Adam for
     every actor update, truss2D_RL.py:629/658/688): with zero moments and step = 1 the bias-corrected moments are g and g^2, so
-    the step is p -= lr * g / (|g| + eps).  Four multi-tensor launches instead of the state allocation (three fills per
-    parameter tensor) and the general update."""
-    ps = [p for p in params if p.grad is not None]
-    if not ps:
-        return
-    grads = [p.grad for p in ps]
-    den = torch._foreach_abs(grads)
-    torch._foreach_add_(den, eps)
-    upd = torch._foreach_div(grads, den)
+    the step is p -= lr * g / (|g| + eps).  A few launches instead of the state allocation (three fills per parameter tensor) and
+    the general update.  flat_grad: the (clipped) gradients of `params` as one vector; default: p.grad of every parameter."""
     with torch.no_grad():
+        if flat_grad is not None:
+            upd = flat_grad / flat_grad.abs().add_(eps)
+            torch._foreach_add_(list(params), [u.view_as(p) for u, p in zip(upd.split([p.numel() for p in params]), params)], alpha=-lr)
+            return
+        ps = [p for p in params if p.grad is not None]
+        if not ps:
+            return
+        grads = [p.grad for p in ps]
+        den = torch._foreach_abs(grads)
+        torch._foreach_add_(den, eps)
+        upd = torch._foreach_div(grads, den)
         torch._foreach_add_(ps, upd, alpha=-lr)
 
 
-def _allreduce_grads(param_lists, dist):
-    """ONE all-reduce (mean over ranks) of the flat gradient buffer of every network in `param_lists` (a list of parameter
-    lists).  The buffer is built and scattered back by multi-tensor launches; inside a hipGraph capture the collective is
-    captured with the update (RCCL kernels on the capture stream)."""
+def _allreduce_flat(flat, dist):
+    """all-reduce (mean over ranks) of an already flat gradient vector, in place"""
     if dist is None or not dist.is_initialized():
-        return
-    grads = [p.grad for ps in param_lists for p in ps if p.grad is not None]
-    if not grads:
-        return
-    world = dist.get_world_size()
-    flat = torch.cat([g.reshape(-1) for g in grads])
+        return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    if world > 1:
-        flat.mul_(1.0 / world)
-    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    world = dist.get_world_size()
+    return flat.mul_(1.0 / world) if world > 1 else flat
 
 
 class multimodals_OneAgent:
@@ -578,6 +579,7 @@ class MADDPG:
         self.max_poss_n_num = max_poss_n_num
         self.device = torch.device(device)
         self.dist = dist
+        self.critics_opt = None      # one SharedStepAdam over the three critics, created once the lazy layers are materialised
         self.gen_agents()
 
     def gen_agents(self):
@@ -612,8 +614,12 @@ class MADDPG:
                     ag.critic_model(S + acts)
                     ag.target_critic_model(S + acts)
                 ag.update_init()
-            if ag.critic_opt is None:
-                ag.critic_opt = SharedStepAdam(ag.critic_model.parameters(), lr=ag.lr, eps=1e-7)   # multi-tensor, usable inside a hipGraph
+        if self.critics_opt is None:
+            # ONE optimiser for the three critics: they are created together and always step together
+            assert len({ag.lr for ag in self.agents}) == 1
+            self.critics_opt = SharedStepAdam([p for ag in self.agents for p in ag.critic_model.parameters()], lr=self.agents[0].lr, eps=1e-7)
+            for ag in self.agents:
+                ag.critic_opt = self.critics_opt
 
     def train(self):
         batch_size = self.batch_size
@@ -667,9 +673,9 @@ class MADDPG:
                 k += 1
         for i, ag in enumerate(agents):
             ag.c_loss.append(losses[i].detach())     # stays on the device: no synchronisation inside the update
-        _allreduce_grads(cps, self.dist)
-        _clip_each([p for cp in cps for p in cp])
-        SharedStepAdam.step_together([ag.critic_opt for ag in agents])
+        allp = [p for cp in cps for p in cp]
+        flat = _allreduce_flat(_flat_grads(allp), self.dist)         # (p.grad keeps the local, unclipped gradient)
+        self.critics_opt.step(_clip_flat(flat, allp))
         # The actor updates stay one after the other: agent i's loss re-evaluates ALL three actors (:617-629), i.e. it sees the
         # weights agents < i have just stepped to -- one collective per actor.  (The other two actors' passes carry no gradient
         # that is asked for -- autograd.grad is taken with respect to agent i's parameters only -- so they run without a graph.)
@@ -686,12 +692,11 @@ class MADDPG:
             ap = list(ag.actor_model.parameters())
             for p in ap:
                 p.grad = None
-            grads = torch.autograd.grad(actor_loss, ap, allow_unused=True)
+            grads = torch.autograd.grad(actor_loss, ap)
             for p, g in zip(ap, grads):
                 p.grad = g
-            _allreduce_grads([ap], self.dist)
-            _clip_each(ap)
-            _fresh_adam_step(ap, ag.lr * 0.1, 1e-7)                                      # a fresh optimiser every call (:629)
+            flat = _clip_flat(_allreduce_flat(_flat_grads(ap), self.dist), ap)
+            _fresh_adam_step(ap, ag.lr * 0.1, 1e-7, flat)                                # a fresh optimiser every call (:629)
             # agent i's weights have just changed: an evaluation of actor i taken before this step must not be reused (the others'
             # stay valid: agents > i have not stepped yet, evaluations of agents < i were taken after their steps)
             frozen = {j: v for j, v in frozen.items() if j != i}

@@ -454,7 +454,7 @@ class BatchedMARL:
                                                                 ag_.target_critic_model)]
                 self.rl._ensure_ready(S, [A[0][0], A[0][1], A[1][0], A[1][1], A[2][0], A[2][1]])
                 snap = [[p.detach().clone() for p in n.parameters()] for n in nets]
-                osnap = [[t.clone() for t in ag_.critic_opt.state_tensors()] for ag_ in self.rl.agents]   # [] = no step taken yet
+                osnap = [t.clone() for t in self.rl.critics_opt.state_tensors()]    # [] = no step taken yet (one optimiser for the three critics)
                 n_loss = [len(ag_.c_loss) for ag_ in self.rl.agents]
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
@@ -483,9 +483,8 @@ class BatchedMARL:
                         for n, sp in zip(nets, snap):
                             for p, v in zip(n.parameters(), sp):
                                 p.copy_(v)
-                        for ag_, sn in zip(self.rl.agents, osnap):
-                            for k, t in enumerate(ag_.critic_opt.state_tensors()):
-                                t.copy_(sn[k]) if sn else t.zero_()
+                        for k, t in enumerate(self.rl.critics_opt.state_tensors()):
+                            t.copy_(osnap[k]) if osnap else t.zero_()
                     for ag_, nl in zip(self.rl.agents, n_loss):
                         del ag_.c_loss[nl:]
 

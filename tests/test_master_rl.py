@@ -235,7 +235,7 @@ def test_update_helpers_match_their_per_tensor_definitions():
     RL._fresh_adam_step(qs, 1e-3, 1e-7)
     for p, q in zip(ps, qs):
         torch.testing.assert_close(q, p, rtol=1e-6, atol=1e-9)
-    # the critic's optimiser: one shared step counter, multi-tensor launches -- six steps against torch.optim.Adam
+    # the critics' optimiser: one shared step counter, flat moments -- six steps against torch.optim.Adam, with the flat clip
     ps, qs = mk(), None
     qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
     ref, mine = torch.optim.Adam(ps, lr=1e-2, eps=1e-7), RL.SharedStepAdam(qs, lr=1e-2, eps=1e-7)
@@ -244,11 +244,22 @@ def test_update_helpers_match_their_per_tensor_definitions():
         for p, q in zip(ps, qs):
             g = torch.randn_like(p) * 10.0 ** (it - 3)
             p.grad, q.grad = g, g.clone()
+        RL._clip_each(ps)
         ref.step()
-        mine.step()
+        mine.step(RL._clip_flat(RL._flat_grads(qs), qs)) if it % 2 else (RL._clip_each(qs), mine.step())
         for p, q in zip(ps, qs):
             torch.testing.assert_close(q, p, rtol=2e-6, atol=1e-8)
-    assert len(mine.state_tensors()) == 1 + 2 * len(qs) and float(mine.step_t) == 6.0
+    assert len(mine.state_tensors()) == 3 and float(mine.step_t) == 6.0 and mine.exp_avg.numel() == sum(q.numel() for q in qs)
+    # ... and the flat form of the actor's one-step Adam
+    ps, qs = mk(), None
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    for p, q in zip(ps, qs):
+        g = torch.randn_like(p)
+        p.grad, q.grad = g, g.clone()
+    RL._fresh_adam_step(ps, 1e-3, 1e-7)
+    RL._fresh_adam_step(qs, 1e-3, 1e-7, RL._flat_grads(qs))
+    for p, q in zip(ps, qs):
+        torch.testing.assert_close(q, p, rtol=1e-6, atol=1e-9)
 
 
 def test_grouped_forward_matches_layerwise():

@@ -37,7 +37,7 @@ ops = [(e.count, e.key) for e in ev if e.device_type == torch.autograd.DeviceTyp
 for c, k in sorted(ops, reverse=True)[:40]:
     print("  op", c, k)
 
-for key in ("aten::div_", "aten::mul_", "aten::add"):
+for key in ("aten::zero_", "aten::fill_", "aten::copy_", "aten::cat", "aten::sum", "aten::add", "aten::mul"):
     evs = [e for e in prof.key_averages(group_by_stack_n=6) if e.key == key]
-    for e in sorted(evs, key=lambda e: -e.count)[:3]:
+    for e in sorted(evs, key=lambda e: -e.count)[:8]:
         print(key, e.count, [fr for fr in e.stack if "site-packages" not in fr and "dist-packages" not in fr][:4] or e.stack[:6])

@@ -64,11 +64,11 @@ with torch.no_grad():
 count("3 critics forward + backward together", critics_fb, True)
 count("actor + critic forward, backward to the actor", actor_fb, True)
 cp = [p for ag_ in rl.agents for p in ag_.critic_model.parameters()]
-count("clip (3 critics)", lambda: RL._clip_each(cp))
-count("Adam step (3 critics together)", lambda: RL.SharedStepAdam.step_together([ag_.critic_opt for ag_ in rl.agents]))
+flat = RL._flat_grads(cp)
+count("critics: flat gradient + clip", lambda: RL._clip_flat(RL._flat_grads(cp), cp))
+count("critics: Adam step", lambda: rl.critics_opt.step(flat))
 ap = list(a0.actor_model.parameters())
-count("clip (actor)", lambda: RL._clip_each(ap))
-count("actor fresh-Adam step", lambda: RL._fresh_adam_step(ap, 1e-4, 1e-7))
+count("actor: flat gradient + clip + fresh-Adam step", lambda: RL._fresh_adam_step(ap, 1e-4, 1e-7, RL._clip_flat(RL._flat_grads(ap), ap)))
 A3 = [(ag[:, a].contiguous(), at[:, a].contiguous()) for a in range(3)]
 nst = [eng._net_state(ns) for ns in NS]
 count("whole update", lambda: rl.train_on_batch(st, nst, A3, R), True)

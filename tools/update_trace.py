@@ -69,6 +69,12 @@ def reduce(d):
            "host_timed_ms_per_update_under_trace": jb["ms_per_update"],
            "distinct_kernels": len(per),
            "top_kernels_by_time": [{"name": k[:160], "launches_per_update": round(v[0], 2), "us_per_update": round(v[1], 1)} for k, v in top]}
+    shapes = {}
+    for f in glob.glob(os.path.join(d, "run_b", "**", "*.db"), recursive=True):
+        c = sqlite3.connect(f)
+        for gx, gy, gz, wx, dur in c.execute("select grid_x, grid_y, grid_z, workgroup_x, duration from kernels where name like '%gcn_level%'"):
+            shapes.setdefault(f"{gx // wx} x {gy} x {gz} workgroups", []).append(dur / 1e3)
+    res["level_kernel_by_grid"] = {k: {"launches": len(v), "median_us": sorted(v)[len(v) // 2], "min_us": min(v)} for k, v in sorted(shapes.items())}
     print(json.dumps(res, indent=1))
 
 

@@ -11,6 +11,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/run_a -o kt -- python
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/run_b -o kt -- python3 tools/update_trace.py run 120 > $OUT/run_b.json 2> $OUT/run_b.err || { tail -5 $OUT/run_b.err; exit 1; }
 python3 tools/update_trace.py reduce $OUT > $OUT/summary.json
 cat $OUT/plain.json
-head -c 2500 $OUT/summary.json
+head -c 1200 $OUT/summary.json
+python3 -c "import json;print(json.dumps(json.load(open('$OUT/summary.json'))['level_kernel_by_grid'],indent=1))"
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*.db" -size +8M -delete
