@@ -650,7 +650,12 @@ class MADDPG:
             # the three next states (one per agent's move, :561-600) go through the target networks as ONE batch of 3 x batch
             # samples, and the three target actors -- then the three target critics -- level by level together
             nb = NS[0][0].shape[0]
-            NSc = [torch.cat([NS[f][k] for f in range(3)], dim=0) for k in range(len(NS[0]))]
+            def three(k):         # a broadcast constant (the shared adjacency A_n, the mask) stays one; the rest is concatenated
+                t = NS[0][k]
+                if t.stride(0) == 0 and all(NS[f][k].stride(0) == 0 and NS[f][k].data_ptr() == t.data_ptr() for f in range(3)):
+                    return t[:1].expand(3 * nb, *t.shape[1:])
+                return torch.cat([NS[f][k] for f in range(3)], dim=0)
+            NSc = [three(k) for k in range(len(NS[0]))]
             na = run_networks([_actor_steps(ag.target_actor_model, self._actor_in(NSc)) for ag in agents], cn)
             tq = run_networks([_critic_steps(ag.target_critic_model, NSc + pair(na, orders[i])) for i, ag in enumerate(agents)], cn)
             # TD targets; `done` never fires in the reference (it compares an action array with `is 1`)

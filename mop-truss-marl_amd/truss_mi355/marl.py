@@ -439,7 +439,9 @@ class BatchedMARL:
         flat_in = list(S) + [t for ns in NS for t in ns] + [t for a in A for t in a] + [R]
         if self._tg is None:
             try:
-                bufs = [t.clone() for t in flat_in]
+                # static input buffers of the graph.  Inputs that are broadcast constants (the shared adjacency A_n, the mask: stride 0
+                # over the batch) are captured as they are -- nothing to copy per update, and the passes see ONE shared adjacency
+                bufs = [t if (t.dim() and t.stride(0) == 0) else t.clone() for t in flat_in]
                 nS = len(S)
 
                 def unpack(b):
@@ -501,7 +503,8 @@ class BatchedMARL:
                 torch.cuda.synchronize(self.device)
                 return self.rl.train_on_batch(S, NS, A, R)
         g, bufs = self._tg
-        torch._foreach_copy_(bufs, flat_in)                               # one multi-tensor launch for the 39 input tensors
+        pairs = [(b, t) for b, t in zip(bufs, flat_in) if b is not t and b.data_ptr() != t.data_ptr()]
+        torch._foreach_copy_([b for b, _ in pairs], [t for _, t in pairs])    # multi-tensor launches for the ~30 input tensors
         g.replay()
 
     # ---- one game step of every env (run() :198-705) ----
