@@ -310,6 +310,7 @@ extern "C" int truss_gcn_level(const truss_gcn_layer_args_t *layers, int32_t n_l
   for (int i = 0; i < n_layers; ++i) {
     const truss_gcn_layer_args_t *a = layers + i;
     if (a->struct_size != sizeof(truss_gcn_layer_args_t)) return tb_fail(TRUSS_EINVAL, "truss_gcn_layer_args_t size mismatch (ABI)");
+    if (a->n_batch == 0) continue;                           // an empty layer: nothing to read, nothing to write
     if (!a->x || !a->adj || !a->w || !a->out) return tb_fail(TRUSS_EINVAL, "truss_gcn_level: a required pointer is NULL");
     if (a->n_batch < 0 || a->n_nodes < 1 || a->k_in < 1 || a->c_out < 1 || a->act < 0 || a->act > 2)
       return tb_fail(TRUSS_EINVAL, "truss_gcn_level: bad sizes / act");

@@ -276,12 +276,13 @@ void gcn_layer_meta(int64_t, int64_t, const at::Tensor &, const at::Tensor &, co
 
 // a whole level of GCN layers in one launch: out[i] = act[i](adj[i] @ (x[i] @ w[i]^T) + bias[i]); x_agg (empty, or one tensor per
 // layer) receives adj[i] @ x[i] == truss_gcn_level
-void gcn_level(int64_t lib, int64_t stream, at::TensorList x, at::TensorList adj, at::TensorList w, at::TensorList bias, at::TensorList out,
-               at::TensorList x_agg, at::IntArrayRef act) {
+void gcn_level(int64_t lib, int64_t stream, at::TensorList x, at::TensorList adj, const c10::List<OT> &nbr, at::TensorList w, at::TensorList bias,
+               at::TensorList out, at::TensorList x_agg, at::IntArrayRef act) {
   const Backend &b = backend(lib);
   TORCH_CHECK(b.gcn_level, "truss_mi355: the bound native library has no truss_gcn_level");
   const size_t L = x.size();
-  TORCH_CHECK(adj.size() == L && w.size() == L && bias.size() == L && out.size() == L && act.size() == L && (x_agg.empty() || x_agg.size() == L),
+  TORCH_CHECK(adj.size() == L && w.size() == L && bias.size() == L && out.size() == L && act.size() == L && (x_agg.empty() || x_agg.size() == L) &&
+                  (nbr.empty() || nbr.size() == L),
               "truss_mi355: gcn_level takes one entry per layer in every list");
   std::vector<truss_gcn_layer_args_t> args(L);
   std::vector<float *> xa(L, nullptr);
@@ -302,6 +303,14 @@ void gcn_level(int64_t lib, int64_t stream, at::TensorList x, at::TensorList adj
     a.x = ptr<const float>(b, x[i], at::kFloat, "x");
     a.adj = ptr<const float>(b, adj[i], at::kFloat, "adj");
     a.a_batch_stride = adj[i].dim() == 3 ? N * N : 0;
+    if (!nbr.empty()) {
+      const OT pat = nbr.get(i);
+      if (pat.has_value() && pat->defined()) {
+        TORCH_CHECK(pat->dim() == 2 && pat->size(0) == N, "truss_mi355: nbr must be [N, K]");
+        a.nbr = ptr<const int16_t>(b, *pat, at::kShort, "nbr");
+        a.k_nbr = (int32_t)pat->size(1);
+      }
+    }
     a.w = ptr<const float>(b, w[i], at::kFloat, "w");
     a.bias = ptr<const float>(b, bias[i], at::kFloat, "bias", C);
     a.out = ptr<float>(b, out[i], at::kFloat, "out");
@@ -312,7 +321,8 @@ void gcn_level(int64_t lib, int64_t stream, at::TensorList x, at::TensorList adj
   }
   check_rc(b, b.gcn_level(args.data(), (int32_t)L, x_agg.empty() ? nullptr : xa.data(), (void *)stream), "truss_gcn_level");
 }
-void gcn_level_meta(int64_t, int64_t, at::TensorList, at::TensorList, at::TensorList, at::TensorList, at::TensorList, at::TensorList, at::IntArrayRef) {}
+void gcn_level_meta(int64_t, int64_t, at::TensorList, at::TensorList, const c10::List<OT> &, at::TensorList, at::TensorList, at::TensorList, at::TensorList,
+                    at::IntArrayRef) {}
 
 // w [C, K] float32 -> out [3, 224, KP] int16 (bfloat16 bit patterns, zero rows / columns beyond C / K): the exact three-term split of the bf16x3 path == truss_gcn_split_w
 void gcn_split_w(int64_t lib, int64_t stream, const at::Tensor &w, const at::Tensor &out) {
@@ -367,7 +377,8 @@ TORCH_LIBRARY(truss_mi355, m) {
   m.def("gcn_layer(int lib, int stream, Tensor x, Tensor adj, Tensor? nbr, Tensor w, Tensor? bias, Tensor(a!) out, int act, bool accumulate, "
         "Tensor? w_split) -> ()");
   m.def("gcn_split_w(int lib, int stream, Tensor w, Tensor(a!) out) -> ()");
-  m.def("gcn_level(int lib, int stream, Tensor[] x, Tensor[] adj, Tensor[] w, Tensor[] bias, Tensor(a!)[] out, Tensor(b!)[] x_agg, int[] act) -> ()");
+  m.def("gcn_level(int lib, int stream, Tensor[] x, Tensor[] adj, Tensor?[] nbr, Tensor[] w, Tensor[] bias, Tensor(a!)[] out, Tensor(b!)[] x_agg, "
+        "int[] act) -> ()");
 }
 TORCH_LIBRARY_IMPL(truss_mi355, CPU, m) {   // the emulator library of the test-suite binds here
   m.impl("step", step);

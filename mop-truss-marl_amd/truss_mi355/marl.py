@@ -203,7 +203,7 @@ def level_forward(lib):
                 ACT.append(code[g.act])
             outs.append(o)
             xaggs.append(xa)
-        ops.call(ops.namespace().gcn_level, ops.bind(lib), ops.stream_of(X[0].device), X, ADJ, W, BIAS, OUT, XAGG, ACT)
+        ops.call(ops.namespace().gcn_level, ops.bind(lib), ops.stream_of(X[0].device), X, ADJ, [], W, BIAS, OUT, XAGG, ACT)
         return outs, xaggs
     return run
 

@@ -424,7 +424,9 @@ extern "C" int truss_gcn_level(const truss_gcn_layer_args_t *layers, int32_t n_l
   for (int l = 0; l < n_layers; ++l) {
     const truss_gcn_layer_args_t *a = layers + l;
     if (a->struct_size != sizeof(truss_gcn_layer_args_t)) return tb_fail(TRUSS_EINVAL, "truss_gcn_level: bad argument block");
-    if (a->accumulate || a->w_bf16x3 || a->n_nodes > 128) return tb_fail(TRUSS_EUNSUPPORTED, "truss_gcn_level: shape / mode outside the kernel's envelope");
+    if (a->n_batch == 0) continue;
+    if (a->accumulate || a->w_bf16x3 || a->n_nodes > 128 || a->k_in > 256)
+      return tb_fail(TRUSS_EUNSUPPORTED, "truss_gcn_level: shape / mode outside the kernel's envelope");
     if (int rc = truss_gcn_layer(a, st)) return rc;
     if (!x_agg || !x_agg[l]) continue;
     const int N = a->n_nodes, K = a->k_in;

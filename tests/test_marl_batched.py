@@ -301,6 +301,61 @@ def _check_gcn_level(lib, device):
     assert calls[-1][2] is False and got.shape == (2, 80, 8)
 
 
+def _check_gcn_level_shapes(lib, device):
+    """`truss_gcn_level` called directly over a mix of shapes in ONE launch, against the float32 PyTorch layer: dense graphs of 16 /
+    32 / 12 nodes (register path, LDS tables, a size that does not divide the 128-row tile), a 24-node graph on a sparsity pattern,
+    k_in 200 / 256 / 8 / 13 / 40 (four full slabs, unaligned input), c_out 224 / 200 / 70 / 3, every activation, a shared and
+    per-graph adjacencies, an empty layer; with and without X' = A X; shapes outside the envelope are refused."""
+    from truss_mi355 import ops
+    torch.manual_seed(4)
+    r = lambda *s: torch.rand(*s, device=device)
+    topo = tm.TrussTopology.grid(12)                                       # 24 nodes
+    tab = topo.neighbor_table()
+    pat = np.zeros((24, 24), bool)
+    for i in range(24):
+        pat[i, tab[i][tab[i] >= 0]] = True
+    cases = [  # B, N, K, C, act, adjacency kind
+        (5, 32, 200, 200, 1, "dense"), (7, 12, 256, 224, 0, "dense"), (33, 16, 8, 3, 2, "dense"), (9, 16, 13, 200, 1, "shared"),
+        (3, 24, 40, 70, 1, "pattern"), (0, 16, 200, 200, 1, "dense"), (64, 16, 200, 200, 1, "dense"), (2, 64, 20, 33, 2, "dense")]
+    X, A, NBR, W, BIAS, ACT, REF = [], [], [], [], [], [], []
+    for B, N, K, C, act, kind in cases:
+        x, w, b = r(B, N, K) - 0.5, (r(C, K) - 0.5) / 4, r(C) - 0.5
+        if kind == "shared":
+            a = torch.softmax(torch.randn(N, N, device=device), -1)
+        elif kind == "pattern":
+            a = r(B, N, N) * torch.tensor(pat, device=device)
+        else:
+            a = torch.softmax(torch.randn(B, N, N, device=device), -1)
+        z = torch.matmul(a, x @ w.t()) + b
+        REF.append((torch.relu(z) if act == 1 else torch.sigmoid(z) if act == 2 else z, torch.matmul(a, x)))
+        X.append(x), A.append(a), W.append(w), BIAS.append(b), ACT.append(act)
+        NBR.append(torch.tensor(tab, device=device) if kind == "pattern" else None)
+    for with_x in (False, True):
+        OUT = [torch.full((x.shape[0], x.shape[1], w.shape[0]), float("nan"), device=device) for x, w in zip(X, W)]
+        XA = [torch.full(x.shape, float("nan"), device=device) for x in X] if with_x else []
+        ops.call(ops.namespace().gcn_level, ops.bind(lib), ops.stream_of(torch.device(device)), X, A, NBR, W, BIAS, OUT, XA, ACT)
+        for k, (o, (ro, rx)) in enumerate(zip(OUT, REF)):
+            torch.testing.assert_close(o, ro, rtol=2e-5, atol=2e-5, msg=lambda m, k=k: f"case {cases[k]}: {m}")
+            if with_x:
+                torch.testing.assert_close(XA[k], rx, rtol=2e-5, atol=2e-6, msg=lambda m, k=k: f"X' of case {cases[k]}: {m}")
+    one = lambda x, a, w: ops.call(ops.namespace().gcn_level, ops.bind(lib), ops.stream_of(torch.device(device)), [x], [a], [], [w], [r(w.shape[0])],
+                                   [torch.empty(x.shape[0], x.shape[1], w.shape[0], device=device)], [], [0])
+    for x, a, w in ((r(1, 80, 8), r(80, 80), r(8, 8)),          # dense adjacency above 64 nodes
+                    (r(1, 8, 8), r(8, 8), r(230, 8)),            # c_out above 224
+                    (r(1, 8, 300), r(8, 8), r(8, 300))):         # k_in above 256
+        with pytest.raises(tm.TrussError):
+            one(x, a, w)
+
+
+def test_gcn_level_shapes_emulated():
+    _check_gcn_level_shapes(pc.emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_gcn_level_shapes_hip():
+    _check_gcn_level_shapes(tm.load(), "cuda")
+
+
 def test_gcn_level_emulated():
     _check_gcn_level(pc.emu_lib(), "cpu")
 

@@ -22,7 +22,7 @@ def level(n_layers, B, N, K, C, want_x, tag):
     O = [torch.empty(B, N, C, device=dev) for _ in range(n_layers)]
     XA = [torch.empty(B * N, K, device=dev) for _ in range(n_layers)] if want_x else []
     act = [1] * n_layers
-    call = lambda: ops.call(ops.namespace().gcn_level, ops.bind(lib), ops.stream_of(torch.device(dev)), X, A, W, Bs, O, XA, act)
+    call = lambda: ops.call(ops.namespace().gcn_level, ops.bind(lib), ops.stream_of(torch.device(dev)), X, A, [], W, Bs, O, XA, act)
     for _ in range(5):
         call()
     torch.cuda.synchronize()
