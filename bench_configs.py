@@ -63,7 +63,10 @@ def mixed_marl(envs=(1024, 512, 256, 128), num_xs=(16, 32, 64, 128), steps=3, tr
     classes = pool.grid_classes(list(num_xs), list(envs))
     eng = marl.MixedMARL(classes, _maddpg(dev), max_front=20, device=dev, replay_capacity=4096, batch_size=32)
     eng.reset([synthetic.random_batch(e.topo, e.B, seed=11 + k) for k, e in enumerate(eng.engines)])
-    n, dt, st = _play(eng, steps, train, 2)
+    # (with training every size class captures its own update graph the first time its turn comes: all of them inside the warm-up)
+    if train:
+        steps = max(steps, len(num_xs))                       # one update per game step, the classes in turn: every class once
+    n, dt, st = _play(eng, steps, train, len(num_xs) + 1 if train else 2)
     return {"config": "mixed Pareto sweep, grid trusses of " + " / ".join(str(2 * n_) for n_ in num_xs) + " nodes, one MADDPG",
             "envs_per_class": list(envs), "game_steps": steps, "train": train, "env_steps": n, "seconds": dt,
             "env_steps_per_s": n / dt, "mean_front": float(st["n_front"].float().mean())}
