@@ -396,7 +396,9 @@ class BatchedMARL:
         x_p, A_p = pareto_graph(pts0, n0, index, self.P)
         if rep > 1:
             x_p, A_p = x_p.repeat(rep, 1, 1), A_p.repeat(rep, 1, 1)
-        c = lambda key: o[key][:k].clone()
+        # views of the env's own observation buffers: the caller is done with them (actor inference, replay rows) before the same env
+        # object analyses / steps again
+        c = lambda key: o[key][:k]
         return dict(x_n=c("x_n"), A_s=c("A_s"), A_n_ts=c("A_n_ts"), A_n_cs=c("A_n_cs"), x_p=x_p, A_p=A_p)
 
     def _net_state(self, S):
