@@ -2,12 +2,13 @@
 // that do not depend on each other -- the layers of one depth of the reference's actors / critics (truss2D_RL.py:49-127), of one
 // network or of several (the three target actors, the three critics ...).  This is the forward of the MADDPG update (batch 32, i.e.
 // 512 .. 1 536 rows per layer): there the layer-by-layer evaluation is bound by its kernel count, not by arithmetic, so the tiling
-// is chosen for LATENCY, not for operand re-use as in truss_gcn.h: grid = (row tiles, layers, 32-column blocks), every workgroup
+// is chosen for LATENCY, not for operand re-use as in truss_gcn.h: grid = (row tiles, layers, 32-column blocks [+ K slabs of X']), every workgroup
 // (4 waves) computes 128 rows x 32 columns of ONE layer -- 924 workgroups for the 33 second-level layers of three critics.  Same
 // evaluation order as the reference, A (X W^T): K slabs of 64 through LDS, v_mfma_f32_32x32x2_f32 with float32 accumulation, the 128 x 32
 // product tile back through LDS, neighbourhood sums from there (six times fewer LDS reads than summing the input rows in each of the
-// seven column blocks), bias / activation, 64-byte row pieces to HBM.  One more slice of the grid stores X' = A X where asked for: the
-// backward pass needs it (dW = dZ^T X').
+// seven column blocks), bias / activation, 64-byte row pieces to HBM.  Extra slices of the grid store X' = A X where asked for (one
+// workgroup per 128 rows x 64 k's): the backward pass needs it (dW = dZ^T X').  A workgroup's time is a chain of memory round trips:
+// its whole K range is requested in one go (see the request sequence below and tools/experiments/README.md for the versions before).
 #pragma once
 
 #define TGL_MAX 24               // layers per launch (24 x 120 bytes of kernel arguments)
@@ -17,10 +18,10 @@ struct GcnLevelDev {
   float *xagg[TGL_MAX];          // [B * N][K] per layer, or nullptr
 };
 
-#define TGL_KS 64                // k's per workgroup of the X' slice of the grid
-#define TGL_LD 68                // floats per LDS row of such a slab (64 + 4 padding: rows 272 bytes apart)
+#define TGL_KS 64                // k's per slab of the product, and per workgroup of the X' slices of the grid
+#define TGL_LD 68                // floats per LDS row of a slab (64 + 4 padding: rows 272 bytes apart)
 #define TGL_HLD 36               // floats per LDS row of the 128 x 32 product tile (32 + 4 padding: rows 144 bytes apart)
-#define TGL_SLABS 4              // slabs of the product, all requested up front: k_in <= 256
+#define TGL_SLABS 4              // slabs of the product (three requested up front, the fourth behind the first): k_in <= 256
 
 #ifdef TRUSS_GCN_STAMPS   // diagnostic build: shader-clock stamps of block (0, 0, 0) / thread 0 (tools/gcn_level_probe.py)
 __device__ unsigned long long g_level_stamps[8];
