@@ -185,7 +185,7 @@ def level_forward(lib):
         X, ADJ, W, BIAS, OUT, XAGG, ACT, outs, xaggs = [], [], [], [], [], [], [], [], []
         for g in groups:
             n, (B, N, K), C = len(g.idx), g.shape, ws[g.idx[0]].shape[0]
-            if N > 64 or C > 224 or xs[g.idx[0]].dtype != torch.float32:
+            if N > 64 or C > 224 or K > 256 or xs[g.idx[0]].dtype != torch.float32:      # outside the kernel's envelope
                 return None
             o = torch.empty((n, B, N, C), dtype=torch.float32, device=xs[g.idx[0]].device)
             xa = torch.empty((n, B * N, K), dtype=torch.float32, device=o.device) if want_grad else None
