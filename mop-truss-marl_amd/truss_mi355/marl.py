@@ -388,12 +388,13 @@ class BatchedMARL:
         self.game_step = 1
 
     # ---- observation tensors in the networks' order ----
-    def _obs(self, env, pts0, n0, index, rep=1, k=None, o=None):
-        """o: observation tensors the analysis / step call has already written (TRUSS_F_EMIT_OBS); None = observation kernel"""
+    def _obs(self, env, pts0, n0, index, rep=1, k=None, o=None, graph=None):
+        """o: observation tensors the analysis / step call has already written (TRUSS_F_EMIT_OBS); None = observation kernel.
+        graph: (x_p, A_p) of the same (pts0, n0, index) if the caller has them already (the candidates see their parent's front)"""
         k = env.B if k is None else k
         if o is None:
             o = env.observe(n_active=k)
-        x_p, A_p = pareto_graph(pts0, n0, index, self.P)
+        x_p, A_p = graph if graph is not None else pareto_graph(pts0, n0, index, self.P)
         if rep > 1:
             x_p, A_p = x_p.repeat(rep, 1, 1), A_p.repeat(rep, 1, 1)
         # views of the env's own observation buffers: the caller is done with them (actor inference, replay rows) before the same env
@@ -550,7 +551,7 @@ class BatchedMARL:
                 a_geo, a_topo = torch.cat(geo, 0).contiguous(), torch.cat(topo, 0).contiguous()
                 oC = eC.step(a_geo, a_topo, clamp_inplace=True, n_active=3 * K, obs=True)   # clamped actions go to the replay (:375);
                 self._steps_dev += 3 * K                                                     # step + next-state observations: one launch
-                NSall = self._obs(eC, p0, nn0, ms, rep=3, k=3 * K, o=oC)
+                NSall = self._obs(eC, p0, nn0, ms, rep=3, k=3 * K, o=oC, graph=(S["x_p"], S["A_p"]))
                 tk = self._tick("candidate step + obs", tk)
                 points = eC.point[:3 * K].view(3, K, 4).permute(1, 0, 2).double().contiguous()
                 cand_y = eC.y[:3 * K].view(3, K, -1).permute(1, 0, 2)
@@ -568,34 +569,33 @@ class BatchedMARL:
                 candY = torch.zeros((B, C3, N), dtype=torch.float32, device=dev)
                 candS = torch.zeros((B, C3, E), dtype=torch.int32, device=dev)
                 pmark = points.clone()
-                pmark[:, :, 2] = torch.where(ok, pmark[:, :, 2], torch.full_like(pmark[:, :, 2], 2.0))
+                pmark[:, :, 2] = torch.where(ok, pmark[:, :, 2], 2.0)
                 candP[idx[:, None], slot] = pmark
                 candY[idx[:, None], slot] = cand_y
                 candS[idx[:, None], slot] = cand_sec
                 wp, wy, ws, wn = self.pts, self.arch_y, self.arch_sec, self.n
-                allp = torch.cat([wp, candP], dim=1).clone()
+                origp = torch.cat([wp, candP], dim=1)
+                allp = origp.clone()
                 dead = arP[None, :] >= wn[:, None]
-                allp[:, :P, 2] = torch.where(dead, torch.full_like(allp[:, :P, 2], 2.0), allp[:, :P, 2])   # infeasible marker
-                fr = RW.front_hv(allp.contiguous(), torch.full((B,), P + C3, dtype=torch.int32, device=dev), None,
-                                 max_front=P, lib=self.lib)
+                allp[:, :P, 2] = torch.where(dead, 2.0, allp[:, :P, 2])                          # infeasible marker
+                fr = RW.front_hv(allp, torch.full((B,), P + C3, dtype=torch.int32, device=dev), None, max_front=P, lib=self.lib)
                 fidx = fr["front_idx"][:, :P].long()
                 take = fidx.clamp(min=0)
                 ally = torch.cat([wy, candY], dim=1)
                 alls = torch.cat([ws, candS], dim=1)
-                origp = torch.cat([wp, candP], dim=1)
                 rows = torch.arange(B, device=dev)[:, None]
-                live = fidx >= 0
-                newp = torch.where(live[:, :, None], origp[rows, take], torch.zeros_like(wp))
-                newp[:, :, 0:2] = torch.minimum(newp[:, :, 0:2], torch.ones_like(newp[:, :, 0:2]))      # :434-436
+                live = (fidx >= 0)[:, :, None]
+                newp = torch.where(live, origp[rows, take], 0.0)
+                newp[:, :, 0:2].clamp_(max=1.0)                                                   # :434-436
                 self.pts = newp
-                self.arch_y = torch.where(live[:, :, None], ally[rows, take], torch.zeros_like(wy))
-                self.arch_sec = torch.where(live[:, :, None], alls[rows, take], torch.zeros_like(ws))
+                self.arch_y = torch.where(live, ally[rows, take], 0.0)
+                self.arch_sec = torch.where(live, alls[rows, take], 0)
                 self.n = fr["n_front"].clamp(max=P).to(torch.int32)
                 tk = self._tick("archive update", tk)
                 # ---- replay (D2): one row per pair with an accepted candidate ----
                 if train:
                     infront = torch.zeros((B, P + C3), dtype=torch.bool, device=dev)
-                    infront.scatter_(1, take, live)
+                    infront.scatter_(1, take, live[:, :, 0])
                     accepted = infront[idx[:, None], P + slot] & ok                          # [K, 3]
                     first_ok = torch.argmax(ok.int(), dim=1)                                   # D4
                     NS = []

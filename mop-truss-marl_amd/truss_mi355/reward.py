@@ -80,25 +80,25 @@ def difference_reward(front_no, n_front_no, pf_hv, n_pf_hv, parent, points, ref_
     pts, n = _append(rep(front_no), rep(n_front_no), rep(points), use4.reshape(4 * B, 3))
     four = front_hv(pts.contiguous(), n, rep(ref_points).contiguous(), max_front, lib)
     hv4 = four["hv_front"].view(4, B)
-    hv_loo, hyperV = [hv4[0], hv4[1], hv4[2]], hv4[3]
+    hyperV = hv4[3]
     metrics = four["metrics"].view(4, B, -1)[3]
     sum_distance, std_cd = metrics[:, 3], metrics[:, 4]
     compareV = front_hv(pf_hv, n_pf_hv, ref_points, 0, lib)["hv_all"]
     real_compareV = front_hv(pf_hv, n_pf_hv, None, 0, lib)["hv_all"]
-    zero = torch.zeros_like(hyperV)
-    hv = [torch.maximum(zero, h - compareV) for h in hv_loo]
-    hyperV = torch.maximum(zero, hyperV - compareV)
-    coef = ((1.0, 0.0), (0.5, 0.5), (0.0, 1.0))
+    # the three agents at once ([B, 3]); per element the same operations in the same order as the per-agent form
+    hv = (hv4[:3].t() - compareV[:, None]).clamp_(min=0)                               # [B, 3]
+    hyperV = (hyperV - compareV).clamp_(min=0)
     npf = n_pf.to(f64)
     m = torch.clamp(real_compareV, min=0.25)
-    R = []
-    for i in range(3):                                                  # both terms use point[0] (master…:348-352)
-        w = coef[i][0] * torch.clamp(parent[:, 0] - points[:, i, 0], min=0) + coef[i][1] * torch.clamp(parent[:, 1] - points[:, i, 0], min=0)
-        w = torch.where(feas[:, i], w, zero)
-        R.append(0.25 * w / (m * npf) + 0.25 * (hyperV - hv[i]) / (m * npf) + 10 * (real_compareV / npf)
-                 - 0.05 * torch.clamp(std_cd, 0, 1) / npf + 0.05 * sum_distance / (2 * m.sqrt() * npf))
+    c0 = torch.tensor((1.0, 0.5, 0.0), dtype=f64, device=points.device)              # coef[i][0]; coef[i][1] = 1 - coef[i][0]
+    p0 = points[:, :, 0]
+    w = c0 * (parent[:, :1] - p0).clamp_(min=0) + (1.0 - c0) * (parent[:, 1:2] - p0).clamp_(min=0)   # both terms use point[0] (master…:348-352)
+    w = torch.where(feas, w, 0.0)
+    mn = (m * npf)[:, None]
+    R = (0.25 * w / mn + 0.25 * (hyperV[:, None] - hv) / mn + (10 * (real_compareV / npf))[:, None]
+         - (0.05 * torch.clamp(std_cd, 0, 1) / npf)[:, None] + (0.05 * sum_distance / (2 * m.sqrt() * npf))[:, None])
     G_U = 20 * real_compareV / npf - std_cd / npf + sum_distance / npf
-    big = torch.full_like(points[:, :, 0], -float("inf"))
-    xmax = torch.maximum(parent[:, 0], torch.where(feas, points[:, :, 0], big).max(dim=1).values)
-    ymax = torch.maximum(parent[:, 1], torch.where(feas, points[:, :, 1], big).max(dim=1).values)
-    return torch.stack(R, dim=1), G_U, xmax, ymax
+    ninf = -float("inf")
+    xmax = torch.maximum(parent[:, 0], torch.where(feas, p0, ninf).max(dim=1).values)
+    ymax = torch.maximum(parent[:, 1], torch.where(feas, points[:, :, 1], ninf).max(dim=1).values)
+    return R, G_U, xmax, ymax
