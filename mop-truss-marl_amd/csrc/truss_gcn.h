@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256) void truss_gcn_split_w_kernel(const float *__r
 typedef __attribute__((address_space(3))) void tg_lds_void;
 typedef __attribute__((address_space(1))) const void tg_glob_void;
 
-template <int NW>
+// KT: neighbourhood terms per row that are gathered (6: the grid trusses -- a node joins at most five others; 9: any pattern the
+// register path takes).  Terms past k_nbr have coefficient 0, but every one of them is two 16-byte LDS reads per slab and thread.
+template <int NW, int KT>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void truss_gcn_layer_bf3_kernel(const GcnLayerDev P, const uint16_t *__restrict__ ws, int KP) {
   constexpr int MT = 32 * NW, NT = 64 * NW, CB = 7, WROWS = 32 * CB;
   static_assert(WROWS == TG_CP, "split-weight image rows");
@@ -413,19 +415,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
   const int ar = tid >> 1, ah = tid & 1, ak = ah * 8;
   const int ag = ar / N, an = ar - ag * N;
   const bool alive = ar < rows;
-  float cf[TG_KREG];
-  uint32_t cj[(TG_KREG + 3) / 4] = {};
+  float cf[KT];
+  uint32_t cj[(KT + 3) / 4] = {};
   const int abase = ((alive ? ag * N : 0)) * TG_LD + ak;
   {
-    int jj[TG_KREG];
+    int jj[KT];
 #pragma unroll
-    for (int t = 0; t < TG_KREG; ++t) {
+    for (int t = 0; t < KT; ++t) {
       const bool use = alive && t < Kn;
       jj[t] = P.nbr ? (int)P.nbr[use ? an * Kn + t : 0] : t;
       jj[t] = use ? jj[t] : -1;
     }
 #pragma unroll
-    for (int t = 0; t < TG_KREG; ++t) {
+    for (int t = 0; t < KT; ++t) {
       const int j = jj[t];
       const float c = P.adj[j < 0 ? 0 : (long)(g0 + ag) * P.a_stride + (long)an * N + j];
       cf[t] = j < 0 ? 0.0f : c;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
   fetch(TG_KS);
   {
     tg_f4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
-    gather(0, TG_KREG, a0, a1);
+    gather(0, KT, a0, a1);
     put_split(0, a0, a1);
   }
   tg_lds_barrier();
@@ -533,8 +535,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
       tg_bf8 wb[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) wb[t] = *(const tg_bf8 *)(sWs + (((buf * 3 + t) * WROWS + col) * 2 + (mh ^ ((col >> 3) & 1))) * 16);
-      if (cb < 4) gather(cb * 2, cb * 2 + 2, a0, a1);                // terms 0..7 between the first four column blocks
-      if (cb == 4) gather(8, TG_KREG, a0, a1);
+      if (cb * 2 < KT) gather(cb * 2, cb * 2 + 2 < KT ? cb * 2 + 2 : KT, a0, a1);   // two terms between the MFMAs of each of the first column blocks
       // small partial products first
       acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2], wb[0], acc[cb], 0, 0, 0);
       acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], wb[1], acc[cb], 0, 0, 0);
@@ -639,15 +640,15 @@ extern "C" int truss_gcn_layer(const truss_gcn_layer_args_t *a, void *stream) {
     const size_t MTb = 32 * (size_t)NW;
     const size_t lds3 = MTb * TG_LD * 4 + 2 * 3 * MTb * 32 + 2 * 3 * 224 * 32;
     const unsigned grid3 = (unsigned)((a->n_batch + P.GB - 1) / P.GB);
-    if (NW == 4) {
-      static TbLdsOptIn optin;
-      if (int rc = optin.ensure((const void *)truss_gcn_layer_bf3_kernel<4>)) return rc;
-      hipLaunchKernelGGL((truss_gcn_layer_bf3_kernel<4>), dim3(grid3), dim3(256), lds3, st, P, a->w_bf16x3, KP);
-    } else {
-      static TbLdsOptIn optin;
-      if (int rc = optin.ensure((const void *)truss_gcn_layer_bf3_kernel<8>)) return rc;
-      hipLaunchKernelGGL((truss_gcn_layer_bf3_kernel<8>), dim3(grid3), dim3(512), lds3, st, P, a->w_bf16x3, KP);
-    }
+#define TG_LAUNCH3(nw, kt)                                                                                                  \
+  do {                                                                                                                      \
+    static TbLdsOptIn optin;                                                                                                \
+    if (int rc = optin.ensure((const void *)truss_gcn_layer_bf3_kernel<nw, kt>)) return rc;                                 \
+    hipLaunchKernelGGL((truss_gcn_layer_bf3_kernel<nw, kt>), dim3(grid3), dim3(64 * nw), lds3, st, P, a->w_bf16x3, KP);      \
+  } while (0)
+    if (NW == 4) { if (P.Kn <= 6) TG_LAUNCH3(4, 6); else TG_LAUNCH3(4, 9); }
+    else { if (P.Kn <= 6) TG_LAUNCH3(8, 6); else TG_LAUNCH3(8, 9); }
+#undef TG_LAUNCH3
     hipError_t e3 = hipGetLastError();
     if (e3 != hipSuccess) return tb_fail(TRUSS_EHIP, std::string("gcn layer (bf16x3) kernel launch failed: ") + hipGetErrorString(e3));
     return TRUSS_OK;

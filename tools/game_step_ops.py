@@ -47,6 +47,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
 ev = prof.key_averages()
 kern = [(e.count, e.device_time_total / 1e3, e.key) for e in ev if e.device_type == torch.autograd.DeviceType.CUDA]
 print("device kernels:", sum(c for c, _, _ in kern), " device time %.2f ms" % sum(t for _, t, _ in kern))
+for c, t, k in sorted(kern, key=lambda r: -r[1])[:24]:
+    print(f"  {c:5d}  {t:7.3f} ms  {k[:100]}")
 ops = [(e.count, e.self_cpu_time_total / 1e3, e.key) for e in ev if e.device_type == torch.autograd.DeviceType.CPU]
 print("host: total self CPU time of operators %.2f ms" % sum(t for _, t, _ in ops))
 for c, t, k in sorted(ops, key=lambda r: -r[1])[:32]:
