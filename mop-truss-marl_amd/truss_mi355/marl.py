@@ -284,8 +284,9 @@ class DeviceReplay:
         self.a_geo, self.a_topo, self.R = f(3, N, 2), f(3, N, 3), f(3)
         self.capacity, self.size, self.head = capacity, 0, 0
 
-    def add(self, sel, S, NS, a_geo, a_topo, R):
-        """append the transitions of the envs where sel[B] is True"""
+    def add(self, sel, S, NS, a_geo, a_topo, R, src=None):
+        """append the transitions of the rows where sel[K] is True.  NS: three dicts (one per agent's next state), or -- with src
+        [K, 3] -- ONE dict of tensors [3, K, ...] from which agent a's next state of row r is taken at [src[r, a], r]"""
         idx = torch.nonzero(sel, as_tuple=False).flatten()
         k = int(idx.numel())
         if k == 0:
@@ -293,10 +294,11 @@ class DeviceReplay:
         if k > self.capacity:
             idx, k = idx[: self.capacity], self.capacity
         pos = (self.head + torch.arange(k, device=idx.device)) % self.capacity
+        pick = None if src is None else src[idx]                               # [k, 3]
         for key in self.KEYS:
             self.S[key][pos] = S[key][idx]
             for a in range(3):
-                self.NS[a][key][pos] = NS[a][key][idx]
+                self.NS[a][key][pos] = NS[a][key][idx] if src is None else NS[key][pick[:, a], idx]
         self.a_geo[pos], self.a_topo[pos], self.R[pos] = a_geo[idx], a_topo[idx], R[idx]
         self.head = (self.head + k) % self.capacity
         self.size = min(self.capacity, self.size + k)
@@ -598,13 +600,13 @@ class BatchedMARL:
                     infront.scatter_(1, take, live[:, :, 0])
                     accepted = infront[idx[:, None], P + slot] & ok                          # [K, 3]
                     first_ok = torch.argmax(ok.int(), dim=1)                                   # D4
-                    NS = []
-                    for a in range(3):
-                        src = torch.where(ok[:, a], torch.full_like(first_ok, a), first_ok)
-                        NS.append({k: NSall[k].view(3, K, *NSall[k].shape[1:])[src, ark] for k in DeviceReplay.KEYS})
+                    # next state of agent a = its own candidate where that is feasible, else the first feasible one (D4): the rows are
+                    # picked from the agent-major candidate tensors inside `add`, for the accepted pairs only
+                    src = torch.where(ok, torch.arange(3, device=dev)[None, :], first_ok[:, None])   # [K, 3]
+                    NSv = {k: NSall[k].view(3, K, *NSall[k].shape[1:]) for k in DeviceReplay.KEYS}
                     ag = a_geo.view(3, K, -1, 2).permute(1, 0, 2, 3)
                     at = a_topo.view(3, K, -1, 3).permute(1, 0, 2, 3)
-                    added += self.replay.add(accepted.any(dim=1), S, NS, ag, at, R.float())
+                    added += self.replay.add(accepted.any(dim=1), S, NSv, ag, at, R.float(), src=src)
                 tk = self._tick("replay", tk)
         # ---- end of the game step (:430-473, 642) ----
         hv = RW.front_hv(self.pts.contiguous(), self.n, None, 0, self.lib)

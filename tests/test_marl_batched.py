@@ -405,3 +405,26 @@ def test_train_graph_matches_eager_updates():
     for a, b in zip(*out):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5)
 
+
+
+def test_replay_add_picks_next_states_like_the_explicit_form():
+    """DeviceReplay.add with `src` (agent a's next state of row r = candidate tensors[src[r, a], r], picked for the accepted rows only)
+    stores exactly what the explicit form (three per-agent dicts over all rows) stores."""
+    torch.manual_seed(1)
+    K, N, P = 9, 4, 3
+    shapes = dict(x_n=(N, 13), A_s=(N, N), A_n_ts=(N, N), A_n_cs=(N, N), x_p=(P, 4), A_p=(P, P))
+    S = {k: torch.rand(K, *s) for k, s in shapes.items()}
+    NSall = {k: torch.rand(3, K, *s) for k, s in shapes.items()}
+    src = torch.randint(0, 3, (K, 3))
+    sel = torch.rand(K) > 0.4
+    ag, at, R = torch.rand(K, 3, N, 2), torch.rand(K, 3, N, 3), torch.rand(K, 3)
+    a, b = marl.DeviceReplay(16, N, P, "cpu"), marl.DeviceReplay(16, N, P, "cpu")
+    ark = torch.arange(K)
+    n1 = a.add(sel, S, [{k: NSall[k][src[:, i], ark] for k in shapes} for i in range(3)], ag, at, R)
+    n2 = b.add(sel, S, NSall, ag, at, R, src=src)
+    assert n1 == n2 == int(sel.sum()) and a.size == b.size and a.head == b.head
+    for k in shapes:
+        assert torch.equal(a.S[k], b.S[k])
+        for i in range(3):
+            assert torch.equal(a.NS[i][k], b.NS[i][k])
+    assert torch.equal(a.a_geo, b.a_geo) and torch.equal(a.R, b.R)
