@@ -77,22 +77,26 @@ def pareto_graph(pts, n, index, max_front):
     B, P, _ = pts.shape
     dev = pts.device
     ar = torch.arange(P, device=dev)
-    valid = ar[None, :] < n[:, None]
-    x = torch.zeros((B, P, 4), dtype=torch.float32, device=dev)
-    x[:, :, 0] = pts[:, :, 0].float()
-    x[:, :, 1] = pts[:, :, 1].float()
-    x[:, :, 2] = (ar[None, :] == index[:, None]).float()
-    x[:, :, 3] = (n.float() / max_front)[:, None]
-    x = x * valid[:, :, None]
-    A = torch.zeros((B, P, P), dtype=torch.float32, device=dev)
-    vf = valid.float()
-    A[:, ar, ar] = vf
-    e = (vf[:, :-1] * vf[:, 1:])
-    A[:, ar[:-1], ar[1:]] = e
-    A[:, ar[1:], ar[:-1]] = e
-    deg = A.sum(dim=2)
-    d = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
-    return x, d[:, :, None] * A * d[:, None, :]
+    vf = (ar[None, :] < n[:, None]).float()                                             # [B, P] 1 on the front's members
+    x = torch.stack([pts[:, :, 0].float(), pts[:, :, 1].float(), (ar[None, :] == index[:, None]).float(),
+                     (n.float() / max_front)[:, None].expand(B, P)], dim=2) * vf[:, :, None]
+    # a path over the members with self loops, symmetrically normalised: deg_i = 1 + (left neighbour) + (right neighbour) on members
+    z = torch.zeros((B, 1), dtype=torch.float32, device=dev)
+    deg = vf * (1.0 + torch.cat([z, vf[:, :-1]], dim=1) + torch.cat([vf[:, 1:], z], dim=1))
+    d = torch.where(deg > 0, deg.pow(-0.5), 0.0)
+    return x, _tridiagonal(P, dev) * d[:, :, None] * d[:, None, :]
+
+
+_TRI: dict = {}
+
+
+def _tridiagonal(P, dev):
+    """[P, P] ones on the three central diagonals (the path graph with self loops), cached per size and device"""
+    key = (P, str(dev))
+    if key not in _TRI:
+        i = torch.arange(P, device=dev)
+        _TRI[key] = ((i[:, None] - i[None, :]).abs() <= 1).float()
+    return _TRI[key]
 
 
 def gcn_aggregate(lib, adj, h, bias, act, nbr=None):

@@ -47,15 +47,14 @@ def _append(base, n_base, extra, use):
     K = extra.shape[1]
     out = torch.zeros((B, P + K, 4), dtype=torch.float64, device=base.device)
     out[:, :P] = base
-    n = n_base.clone().to(torch.int64)
-    rows = torch.arange(B, device=base.device)
-    for k in range(K):
-        u = use[:, k]
-        idx = torch.where(u, n, torch.full_like(n, P + K - 1))          # unused rows land in a scratch slot ...
-        keep = out[rows, idx]
-        out[rows, idx] = torch.where(u[:, None], extra[:, k], keep)    # ... and leave it untouched
-        n = n + u.to(torch.int64)
-    return out, n.to(torch.int32)
+    n = n_base.to(torch.int64)
+    c = torch.cumsum(use.to(torch.int64), dim=1)
+    # row k of `extra` goes to slot n + (used rows before it); unused rows are sent to the last slot with the value it already holds
+    # (zero: it is the target of a used row only when all K rows are used, and then nothing is unused)
+    idx = torch.where(use, n[:, None] + c - 1, P + K - 1)
+    rows = torch.arange(B, device=base.device)[:, None]
+    out[rows, idx] = torch.where(use[:, :, None], extra, 0.0)
+    return out, (n + c[:, -1]).to(torch.int32)
 
 
 def difference_reward(front_no, n_front_no, pf_hv, n_pf_hv, parent, points, ref_points, n_pf, max_front=20, lib=None):
