@@ -432,7 +432,7 @@ class BatchedMARL:
                 if explore:                                           # truss2D_RL.OUNoise.gen_noise per scalar (:41-48), all columns at once
                     for out, noises in ((g, ag.noise_geo), (t, ag.noise_topo)):
                         th_dt, mu, sg = self._noise_vectors(noises)
-                        out += th_dt * (mu - out) + sg * torch.randn(out.shape, device=out.device, generator=self.gen)
+                        out.addcmul_(th_dt, mu - out).addcmul_(sg, torch.randn(out.shape, device=out.device, generator=self.gen))
                 geo.append(g.float().contiguous())
                 topo.append(t.float().contiguous())
         return geo, topo
@@ -528,7 +528,7 @@ class BatchedMARL:
         tk = time.perf_counter()
         dev = self.device
         N, E = self.topo.N, self.topo.E
-        arP = torch.arange(P, device=dev)
+        arP = self._const("arP", lambda: torch.arange(P, device=dev))
         n_max = int(n0.max().item())
         for g0 in range(0, n_max, Gm):                                # member groups whose candidates fit one cull
             # live (env, member) pairs of this group, member-major: pair k = (env pb[k], member pm[k])
@@ -566,12 +566,12 @@ class BatchedMARL:
                                                   nn0, max_front=P, lib=self.lib)
                 rsum.index_add_(0, idx, R)
                 tk = self._tick("reward", tk)
-                ok = (points[:, :, 2] <= 1) & (points[:, :, 3] <= 1)                          # archive candidates (:372)
+                ok = (points[:, :, 2:4] <= 1).all(dim=2)                                      # archive candidates (:372)
                 # ---- archive update (D1): front of (working archive + the feasible candidates of this chunk's members) ----
                 C3 = 3 * Gm
-                slot = ((ms - g0) * 3)[:, None] + torch.arange(3, device=dev)[None, :]        # [K, 3] candidate slot of (pair, agent)
-                candP = torch.zeros((B, C3, 4), dtype=torch.float64, device=dev)
-                candP[:, :, 2] = 2.0                                                          # empty slot = infeasible row
+                slot = ((ms - g0) * 3)[:, None] + self._const("ar3", lambda: torch.arange(3, device=dev)[None, :])   # [K, 3] candidate slot of (pair, agent)
+                candP = self._const("candP", lambda: torch.tensor([0.0, 0.0, 2.0, 0.0], dtype=torch.float64, device=dev).expand(B, C3, 4)).clone()
+                #                                                                               (empty slot = infeasible row: [0, 0, 2, 0])
                 candY = torch.zeros((B, C3, N), dtype=torch.float32, device=dev)
                 candS = torch.zeros((B, C3, E), dtype=torch.int32, device=dev)
                 pmark = points.clone()
@@ -584,19 +584,20 @@ class BatchedMARL:
                 allp = origp.clone()
                 dead = arP[None, :] >= wn[:, None]
                 allp[:, :P, 2] = torch.where(dead, 2.0, allp[:, :P, 2])                          # infeasible marker
-                fr = RW.front_hv(allp, torch.full((B,), P + C3, dtype=torch.int32, device=dev), None, max_front=P, lib=self.lib)
+                fr = RW.front_hv(allp, self._const("full_front", lambda: torch.full((B,), P + C3, dtype=torch.int32, device=dev)), None,
+                                 max_front=P, lib=self.lib)
                 fidx = fr["front_idx"][:, :P].long()
                 take = fidx.clamp(min=0)
                 ally = torch.cat([wy, candY], dim=1)
                 alls = torch.cat([ws, candS], dim=1)
-                rows = torch.arange(B, device=dev)[:, None]
+                rows = self._const("rows", lambda: torch.arange(B, device=dev)[:, None])
                 live = (fidx >= 0)[:, :, None]
                 newp = torch.where(live, origp[rows, take], 0.0)
                 newp[:, :, 0:2].clamp_(max=1.0)                                                   # :434-436
                 self.pts = newp
                 self.arch_y = torch.where(live, ally[rows, take], 0.0)
                 self.arch_sec = torch.where(live, alls[rows, take], 0)
-                self.n = fr["n_front"].clamp(max=P).to(torch.int32)
+                self.n = fr["n_front"].clamp(max=P)                                           # (int32 already)
                 tk = self._tick("archive update", tk)
                 # ---- replay (D2): one row per pair with an accepted candidate ----
                 if train:
@@ -621,6 +622,13 @@ class BatchedMARL:
         tk = self._tick("train", tk)
         return dict(hv=hv["hv_front"], n_front=self.n.clone(), sum_distance=hv["metrics"][:, 3], reward=rsum, replay_added=added,
                     replay_size=self.replay.size)
+
+    def _const(self, name, make):
+        """small constant device tensors of the game step (index ranges, fill patterns), made once"""
+        c = self.__dict__.setdefault("_consts", {})
+        if name not in c:
+            c[name] = make()
+        return c[name]
 
     def train_from_replay(self, train_iters: int = 1):
         """`train_iters` MADDPG updates on batches sampled from this engine's replay (when it holds a batch; collective
