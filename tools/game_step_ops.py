@@ -51,5 +51,11 @@ for c, t, k in sorted(kern, key=lambda r: -r[1])[:24]:
     print(f"  {c:5d}  {t:7.3f} ms  {k[:100]}")
 ops = [(e.count, e.self_cpu_time_total / 1e3, e.key) for e in ev if e.device_type == torch.autograd.DeviceType.CPU]
 print("host: total self CPU time of operators %.2f ms" % sum(t for _, t, _ in ops))
-for c, t, k in sorted(ops, key=lambda r: -r[1])[:32]:
+for c, t, k in sorted(ops, key=lambda r: -r[1])[:12]:
     print(f"  {c:5d}  {t:7.2f} ms  {k[:90]}")
+print("operators that launch, by count:")
+skip = ("aten::as_strided", "aten::view", "aten::reshape", "aten::slice", "aten::select", "aten::expand", "aten::unsqueeze", "aten::empty", "aten::empty_strided",
+        "aten::empty_like", "aten::permute", "aten::transpose", "aten::t", "aten::_unsafe_view", "aten::resize_", "aten::squeeze", "aten::alias", "aten::detach",
+        "aten::to", "aten::result_type", "aten::item", "aten::_local_scalar_dense", "aten::lift_fresh", "aten::view_as", "aten::narrow", "aten::contiguous")
+for c, t, k in sorted((o for o in ops if o[2].startswith("aten::") and o[2] not in skip), key=lambda r: -r[0])[:30]:
+    print(f"  {c:5d}  {k}")
